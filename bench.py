@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- PASTA-3 transcipherings/sec on MI355X (BASELINE.json metric).
+
+step      = one pass of the hot path (hhe_pasta3_transcipher) over one batch of B independent
+            128-word blocks per rank (BASELINE config 2: N=2^15, 4x60-bit primes, t=65537, B=256).
+value     = transcipherings all ranks completed / max-over-ranks time (inputs resident in HBM;
+            only the 1 KiB/block of symmetric ciphertext words crosses PCIe inside the timed region).
+roofline  = SURVEY 8(d): algorithmic bytes of one transciphering (A_block) x blocks per launch of the
+            path / its HIP-event time, against 8 TB/s; plus the dominant kernel measured by itself.
+cpu_baseline = the CPU oracle (a C port of the reference schedule) on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "privacy-preserving-ml-through-hhe_amd"
+
+# BASELINE config 2: CoeffModulus::Create(32768, {60,60,60,60})
+Q_CONFIG2 = [1152921504595968001, 1152921504597016577, 1152921504598720513, 1152921504606584833]
+T_PLAIN = 65537
+LOGN = 15
+
+
+def a_block_bytes(n, L, K):
+    """SURVEY 8(d) op-level algorithmic bytes of one transciphering"""
+    P = 8 * n
+    ks = 4 * L + 2 * L * K
+    units = 518 * ks + 514 * 5 * L + 522 * 6 * L + 5 * 3 * L + 4 * L + 2 * 5 * L + 2 * 7 * L + 4 * (5 * L + 2 * L * K)
+    return units * P
+
+
+def synthetic_keys(rng, q, n):
+    """uniform key-switch key words of SEAL's layout [L][2][K][N] (values irrelevant to throughput)"""
+    K, L = len(q), len(q) - 1
+    k = np.empty((L, 2, K, n), np.uint64)
+    for j in range(K):
+        k[:, :, j, :] = rng.integers(0, q[j], size=(L, 2, n), dtype=np.uint64)
+    return k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="transcipherings per rank per step")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-blocks-per-thread", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    sh = importlib.import_module(PKG + ".sharding")
+    api = importlib.import_module(PKG + ".api")
+    rank, world, local_rank = sh.rank_world()
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sh.init_process_group("nccl")  # RCCL; used for the barrier / time reduction only
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    lib = api.load_library()
+
+    n, q, t = 1 << LOGN, Q_CONFIG2, T_PLAIN
+    K, L = len(q), len(q) - 1
+    B = args.batch
+    X = api.Context(LOGN, q, t, device=local_rank, lib=lib)
+    stream = torch.cuda.Stream(device=dev)
+    X.set_stream(stream.cuda_stream)
+    rng = np.random.default_rng(1234)
+    # synthetic key material + encrypted PASTA key (uniform words; same shapes as SEAL's objects)
+    rk = synthetic_keys(rng, q, n)
+    gks = {}
+    for step in (-1, 128, 0):
+        e = X.query("galois_elt", step)
+        gks[e] = synthetic_keys(rng, q, n)
+        X.set_galois_key(e, gks[e])
+    X.set_relin_key(rk)
+    enc_key = np.stack([rng.integers(0, q[j], size=(2, n), dtype=np.uint64) for j in range(L)], axis=1)
+    d_key = torch.from_numpy(enc_key.view(np.int64)).to(dev)
+    # B independent 128-word symmetric ciphertext blocks (uniform words < t), block counter 0 (config 2)
+    cw = rng.integers(0, t, size=(B, 128), dtype=np.uint64)
+    ncw = np.full(B, 128, np.uint32)
+    bidx = np.zeros(B, np.uint64)
+    out = torch.zeros((B, 2, L, n), dtype=torch.int64, device=dev)
+    X.reserve(B)
+
+    def step():
+        X.transcipher(d_key, cw, ncw, bidx, out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sh.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    sh.barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    el_max, units = sh.reduce_max_sum(elapsed, B * args.steps, device=dev if world > 1 else "cpu")
+    value = units / el_max
+
+    # dominant kernel by itself: batched forward NTT (both passes) over the key-switch digit polys
+    npoly = B * L * K
+    scratch = torch.zeros((npoly, n), dtype=torch.int64, device=dev)
+    X.ntt(scratch, npoly, 0, K, False)
+    torch.cuda.synchronize()
+    reps = 10
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record(stream)
+    for _ in range(reps):
+        X.ntt(scratch, npoly, 0, K, False)
+    k1.record(stream)
+    torch.cuda.synchronize()
+    ntt_ms = k0.elapsed_time(k1) / reps
+    ntt_alg = 2 * npoly * n * 8  # read + write each polynomial once
+    del scratch
+
+    res = None
+    if rank == 0:
+        A = a_block_bytes(n, L, K)
+        path_ms = dev_ms / args.steps
+        achieved = A * B / (path_ms * 1e-3) / 1e9
+        res = {
+            "metric": "PASTA-3 transcipherings/sec (N=2^15, 4 RNS limbs)", "value": value, "unit": "transcipherings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: N=2^15, coeff_modulus 4x60-bit (L=3,K=4), t=65537, "
+                                   f"batch-{B} independent 128-word PASTA-3 blocks per GPU, block counter 0",
+                       "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",
+                         "algorithmic_bytes_per_unit": A, "units_per_launch": B, "launch_ms": path_ms,
+                         "dominant_kernel": {"name": "ntt_pass_kernel (forward, both passes)", "polys": npoly,
+                                             "algorithmic_bytes": ntt_alg, "ms": ntt_ms,
+                                             "achieved_GBps": ntt_alg / (ntt_ms * 1e-3) / 1e9,
+                                             "frac": ntt_alg / (ntt_ms * 1e-3) / 1e9 / 8000.0}},
+        }
+        if world == 1 and args.cpu_baseline:
+            import oracle as orc  # CPU baseline leg only
+            O = orc.Oracle(LOGN, q, t)
+            threads = os.cpu_count() or 1
+            nb = threads * args.cpu_blocks_per_thread
+            elts = sorted(gks)
+            gk = orc.GaloisKeys(elts, np.stack([gks[e] for e in elts]))
+            c0 = time.perf_counter()
+            ref = O.transcipher_batch(enc_key, rk, gk, cw[:nb], ncw[:nb], bidx[:nb], threads=threads)
+            cpu_s = time.perf_counter() - c0
+            got = out[:1].cpu().numpy().view(np.uint64)
+            res["cpu_baseline"] = {"value": nb / cpu_s, "unit": "transcipherings/s", "cores": threads, "kind": "port",
+                                   "sample": f"{nb} blocks of the same workload ({args.cpu_blocks_per_thread}/thread, OpenMP over blocks), {cpu_s:.1f} s",
+                                   "matches_gpu_item0": bool((got[0] == ref[0]).all())}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    X.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

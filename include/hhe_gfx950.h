@@ -1,0 +1,127 @@
+/*
+ * hhe_gfx950.h -- C ABI of libhhe_gfx950.so: the MI355X (gfx950) implementation of the
+ * CSP-side hot path of harpocrates-project/Privacy-Preserving-ML-through-HHE:
+ * PASTA-3 -> BFV transciphering followed by the packed BFV linear layer.
+ *
+ * Plain C types only.  Every entry point returns 0 on success, non-zero on failure
+ * (hhe_last_error() gives the message; INTEGRATION.md maps codes to the C++ exceptions
+ * the reference throws).  "dptr" arguments are DEVICE pointers (HBM, uint64 words);
+ * "hptr" arguments are host pointers.  Ciphertexts use SEAL's in-memory layout
+ * [poly][limb][coeff] (seal/ciphertext.h:701-715) at the data level (L = K-1 limbs), in
+ * coefficient (non-NTT) form, batches are contiguous: [B][2][L][N].
+ * Key-switch keys use KSwitchKeys::data()[index][digit].data() layout, i.e.
+ * [L digits][2][K][N] in NTT form (seal/kswitchkeys.h:90-130).
+ *
+ * Reference interface each entry replaces is cited as (file:line) relative to the
+ * reference repository root.
+ */
+#ifndef HHE_GFX950_H
+#define HHE_GFX950_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hhe_ctx hhe_ctx;
+
+enum {
+    HHE_OK = 0,
+    HHE_ERR_INVALID = 1,        /* std::invalid_argument in SEAL / the reference        */
+    HHE_ERR_NO_GALOIS_KEY = 2,  /* SEAL: "Galois key not present" (evaluator.h:955-1060) */
+    HHE_ERR_TOO_FEW_SLOTS = 3,  /* "too little slots for matmul implementation!" (src/pasta/pasta_3_seal.cpp:376-377) */
+    HHE_ERR_DEVICE = 4,         /* HIP runtime failure                                    */
+    HHE_ERR_NO_RELIN_KEY = 5,
+    HHE_ERR_CAPACITY = 6
+};
+
+const char *hhe_last_error(void);
+/* "hip-gfx950" for the product library */
+const char *hhe_backend(void);
+
+/* ---- context: replaces SEALZpCipher::create_context / sealhelper::get_seal_context
+ *      (src/pasta/SEAL_Cipher.cpp:38-68, src/util/sealhelper.cpp:8-41) with an explicit
+ *      prime list: q[K] = coeff_modulus (last = special key-switch prime), t = plain_modulus.
+ *      Derives NTT tables, BatchEncoder map, BEHZ base exactly as SEAL 4.0.0 does. ---- */
+int hhe_ctx_create(int logn, int K, const uint64_t *q_hptr, uint64_t t, int device, hhe_ctx **out);
+void hhe_ctx_destroy(hhe_ctx *c);
+/* run all work of this context on an existing HIP stream (hipStream_t); NULL = default stream */
+int hhe_ctx_set_stream(hhe_ctx *c, void *hip_stream);
+/* size per-batch workspaces for up to max_batch ciphertexts (allocated once, reused) */
+int hhe_ctx_reserve(hhe_ctx *c, size_t max_batch);
+int hhe_ctx_sync(hhe_ctx *c);
+/* derived parameters, for cross-checking against SEAL's context: what in
+ * {"root" i<K, "bsk" i<=L (B_0.., m_sk), "gamma", "galois_elt" i=step} */
+uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i);
+
+/* ---- keys: the by-value seal::RelinKeys / seal::GaloisKeys members of SEALZpCipher
+ *      (src/pasta/SEAL_Cipher.h:28-31; ctor SEAL_Cipher.cpp:9-36).  Uploaded once, cached in HBM. ---- */
+int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk_hptr);
+int hhe_set_galois_key(hhe_ctx *c, uint32_t galois_elt, const uint64_t *ksk_hptr);
+int hhe_has_galois_key(const hhe_ctx *c, uint32_t galois_elt);
+
+/* ---- device memory helpers for callers without their own HIP allocator ---- */
+void *hhe_malloc(size_t bytes);
+void hhe_free(void *dptr);
+int hhe_copy_h2d(hhe_ctx *c, void *dptr, const void *hptr, size_t bytes);
+int hhe_copy_d2h(hhe_ctx *c, void *hptr, const void *dptr, size_t bytes);
+
+/* ---- BFV primitives on device batches (seal::Evaluator / BatchEncoder as used by the path) ---- */
+/* util::ntt_negacyclic_harvey / inverse (seal/util/ntt.h:231,303): polys [count][N], modulus of
+ * poly p = mod_base + p % mod_cycle (0..K-1 coeff primes, K..K+L Bsk, K+L+1 = t), in place */
+int hhe_ntt(hhe_ctx *c, uint64_t *polys_dptr, size_t count, int mod_base, int mod_cycle, int inverse);
+/* BatchEncoder::encode (seal/batchencoder.h:80): vals [B][count] -> plain [B][N] */
+int hhe_encode(hhe_ctx *c, const uint64_t *vals_dptr, size_t B, size_t count, uint64_t *plain_dptr);
+/* Evaluator::add_inplace / negate_inplace (seal/evaluator.h:92-132); size = polys per ct */
+int hhe_add(hhe_ctx *c, const uint64_t *a_dptr, const uint64_t *b_dptr, uint64_t *out_dptr, size_t B, int size);
+int hhe_negate(hhe_ctx *c, const uint64_t *a_dptr, uint64_t *out_dptr, size_t B, int size);
+/* Evaluator::add_plain / sub_plain (seal/evaluator.h:665-680); plain [B][N] or [1][N] if bcast */
+int hhe_add_plain(hhe_ctx *c, const uint64_t *ct_dptr, const uint64_t *plain_dptr, int plain_bcast,
+                  int subtract, uint64_t *out_dptr, size_t B);
+/* Evaluator::multiply_plain (seal/evaluator.h:729-747) */
+int hhe_multiply_plain(hhe_ctx *c, const uint64_t *ct_dptr, const uint64_t *plain_dptr, int plain_bcast,
+                       uint64_t *out_dptr, size_t B);
+/* Evaluator::apply_galois (seal/evaluator.h:889) */
+int hhe_apply_galois(hhe_ctx *c, const uint64_t *ct_dptr, uint32_t galois_elt, uint64_t *out_dptr, size_t B);
+/* Evaluator::rotate_rows / rotate_columns incl. NAF fallback (seal/evaluator.h:955-1060) */
+int hhe_rotate_rows(hhe_ctx *c, const uint64_t *ct_dptr, int step, uint64_t *out_dptr, size_t B);
+int hhe_rotate_columns(hhe_ctx *c, const uint64_t *ct_dptr, uint64_t *out_dptr, size_t B);
+/* Evaluator::multiply (seal/evaluator.h:214-277; BEHZ) -> size-3 ct [B][3][L][N] */
+int hhe_multiply(hhe_ctx *c, const uint64_t *a_dptr, const uint64_t *b_dptr, uint64_t *out3_dptr, size_t B);
+/* Evaluator::relinearize_inplace (seal/evaluator.h:301-304) size 3 -> 2 */
+int hhe_relinearize(hhe_ctx *c, const uint64_t *a3_dptr, uint64_t *out_dptr, size_t B);
+
+/* ---- the hot path ---- */
+/* PASTA_SEAL::decomposition / HE_decrypt (src/pasta/pasta_3_seal.cpp:106-172 / :42-104), batched over
+ * independent blocks: item i transciphers the <=128 symmetric-ciphertext words cw[i][0..ncw[i]) that
+ * were PASTA-encrypted with block counter block_index[i] (nonce 123456789) under the key whose BFV
+ * encryption is enc_key (ONE ciphertext [2][L][N], shared by the batch: enc_ssk[0]).
+ * cw_hptr [B][128] uint64 host, ncw_hptr [B], block_index_hptr [B]; out [B][2][L][N] device.
+ * Needs relin key + Galois keys for steps {-1, +128 (if N/2 != 128), columns} (add_gk_indices :190-201);
+ * use_bsgs!=0 selects PASTA_SEAL::babystep_giantstep (:267-366) and additionally steps -16k, k=1..7. */
+int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key_dptr, const uint64_t *cw_hptr,
+                           const uint32_t *ncw_hptr, const uint64_t *block_index_hptr, size_t B,
+                           int use_bsgs, uint64_t *out_dptr);
+/* drop cached per-block public tables (matrices depend only on (nonce, block index)) */
+void hhe_pasta3_clear_block_cache(hhe_ctx *c);
+/* SEALZpCipher::mask (src/pasta/SEAL_Cipher.cpp:161-166): mask_vals_hptr[count], shared by the batch */
+int hhe_mask(hhe_ctx *c, const uint64_t *ct_dptr, const uint64_t *mask_vals_hptr, size_t count,
+             uint64_t *out_dptr, size_t B);
+/* SEALZpCipher::flatten (src/pasta/SEAL_Cipher.cpp:170-181): blocks [S][nblocks][2][L][N] -> out [S][2][L][N] */
+int hhe_flatten(hhe_ctx *c, const uint64_t *blocks_dptr, size_t nblocks, uint64_t *out_dptr, size_t S);
+/* FC row: sealhelper::packed_enc_multiply + Evaluator::relinearize_inplace + sealhelper::encrypted_vec_sum
+ * (src/util/sealhelper.cpp:268-274, src/examples/CSP/CSP.cpp:306, sealhelper.cpp:379-392).
+ * vi [B][2][L][N]; w: weight-row ciphertexts [W][2][L][N]; item i uses w[i % W]. out [B][2][L][N];
+ * the neuron's value is slot n_inputs-1 of the decryption. */
+int hhe_fc_row(hhe_ctx *c, const uint64_t *vi_dptr, const uint64_t *w_dptr, size_t W, size_t n_inputs,
+               uint64_t *out_dptr, size_t B);
+
+/* PASTA-3 public randomness for one block as the kernels consume it (host; src/pasta/pasta_3_plain.cpp:56-119,286-295):
+ * mats [4][2][128][128], rcs [4][2][128] */
+int hhe_pasta3_block_randomness(uint64_t t, uint64_t block_index, uint64_t *mats_hptr, uint64_t *rcs_hptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

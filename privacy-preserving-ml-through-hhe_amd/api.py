@@ -1,0 +1,202 @@
+"""ctypes binding of libhhe_gfx950.so (include/hhe_gfx950.h).
+
+The library is the product: hand-written gfx950 kernels behind a C ABI.  This module
+only marshals pointers; device memory comes from PyTorch-ROCm tensors (plumbing).
+There is no CPU path: if the HIP library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhhe_gfx950.so")
+PASTA_T = 128
+
+u64p = C.POINTER(C.c_uint64)
+
+
+class HheError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hhe error {code}: {msg}")
+        self.code = code
+
+
+# error codes of include/hhe_gfx950.h
+ERR_INVALID, ERR_NO_GALOIS_KEY, ERR_TOO_FEW_SLOTS, ERR_DEVICE, ERR_NO_RELIN_KEY = 1, 2, 3, 4, 5
+
+_SYMBOLS = [
+    "hhe_last_error", "hhe_backend", "hhe_ctx_create", "hhe_ctx_destroy", "hhe_ctx_set_stream",
+    "hhe_ctx_reserve", "hhe_ctx_sync", "hhe_ctx_query", "hhe_set_relin_key", "hhe_set_galois_key",
+    "hhe_has_galois_key", "hhe_malloc", "hhe_free", "hhe_copy_h2d", "hhe_copy_d2h", "hhe_ntt",
+    "hhe_encode", "hhe_add", "hhe_negate", "hhe_add_plain", "hhe_multiply_plain", "hhe_apply_galois",
+    "hhe_rotate_rows", "hhe_rotate_columns", "hhe_multiply", "hhe_relinearize",
+    "hhe_pasta3_transcipher", "hhe_pasta3_clear_block_cache", "hhe_mask", "hhe_flatten", "hhe_fc_row",
+    "hhe_pasta3_block_randomness",
+]
+
+
+def exported_symbols():
+    return list(_SYMBOLS)
+
+
+def load_library(path=None):
+    """Load the C-ABI library.  Default: the in-tree gfx950 build; anything else must be passed explicitly."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the gfx950 HIP library is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for s in _SYMBOLS:
+        getattr(lib, s)  # AttributeError if the ABI is incomplete
+    lib.hhe_last_error.restype = C.c_char_p
+    lib.hhe_backend.restype = C.c_char_p
+    lib.hhe_ctx_query.restype = C.c_uint64
+    lib.hhe_ctx_query.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.hhe_malloc.restype = C.c_void_p
+    lib.hhe_malloc.argtypes = [C.c_size_t]
+    lib.hhe_free.argtypes = [C.c_void_p]
+    lib.hhe_ctx_destroy.argtypes = [C.c_void_p]
+    lib.hhe_pasta3_clear_block_cache.argtypes = [C.c_void_p]
+    return lib
+
+
+def _ptr(x):
+    """address of a torch tensor / numpy array / raw int"""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return C.c_void_p(x.ctypes.data)
+    assert x.is_contiguous()
+    return C.c_void_p(x.data_ptr())
+
+
+class Context:
+    """One BFV context on one GPU (hhe_ctx)."""
+
+    def __init__(self, logn, q, t, device=0, lib=None):
+        self.lib = lib or load_library()
+        self.logn, self.n, self.q, self.t = logn, 1 << logn, [int(v) for v in q], int(t)
+        self.K, self.L = len(q), len(q) - 1
+        qa = np.asarray(self.q, dtype=np.uint64)
+        h = C.c_void_p()
+        self._chk(self.lib.hhe_ctx_create(C.c_int(logn), C.c_int(self.K), _ptr(qa), C.c_uint64(t), C.c_int(device), C.byref(h)))
+        self.h = h
+        self.ct_shape = (2, self.L, self.n)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HheError(rc, self.lib.hhe_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hhe_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def backend(self):
+        return self.lib.hhe_backend().decode()
+
+    def query(self, what, i=0):
+        return int(self.lib.hhe_ctx_query(self.h, what.encode(), C.c_int(i)))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.hhe_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def reserve(self, B):
+        self._chk(self.lib.hhe_ctx_reserve(self.h, C.c_size_t(B)))
+
+    def sync(self):
+        self._chk(self.lib.hhe_ctx_sync(self.h))
+
+    def set_relin_key(self, ksk):
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        assert ksk.shape == (self.L, 2, self.K, self.n)
+        self._chk(self.lib.hhe_set_relin_key(self.h, _ptr(ksk)))
+
+    def set_galois_key(self, elt, ksk):
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        assert ksk.shape == (self.L, 2, self.K, self.n)
+        self._chk(self.lib.hhe_set_galois_key(self.h, C.c_uint32(elt), _ptr(ksk)))
+
+    def has_galois_key(self, elt):
+        return bool(self.lib.hhe_has_galois_key(self.h, C.c_uint32(elt)))
+
+    # ---- primitives on device batches (arguments: torch cuda tensors / raw addresses) ----
+    def ntt(self, polys, count, mod_base, mod_cycle, inverse=False):
+        self._chk(self.lib.hhe_ntt(self.h, _ptr(polys), C.c_size_t(count), C.c_int(mod_base), C.c_int(mod_cycle), C.c_int(int(inverse))))
+
+    def encode(self, vals, B, count, plain):
+        self._chk(self.lib.hhe_encode(self.h, _ptr(vals), C.c_size_t(B), C.c_size_t(count), _ptr(plain)))
+
+    def add(self, a, b, out, B, size=2):
+        self._chk(self.lib.hhe_add(self.h, _ptr(a), _ptr(b), _ptr(out), C.c_size_t(B), C.c_int(size)))
+
+    def negate(self, a, out, B, size=2):
+        self._chk(self.lib.hhe_negate(self.h, _ptr(a), _ptr(out), C.c_size_t(B), C.c_int(size)))
+
+    def add_plain(self, ct, plain, out, B, bcast=False, subtract=False):
+        self._chk(self.lib.hhe_add_plain(self.h, _ptr(ct), _ptr(plain), C.c_int(int(bcast)), C.c_int(int(subtract)), _ptr(out), C.c_size_t(B)))
+
+    def multiply_plain(self, ct, plain, out, B, bcast=False):
+        self._chk(self.lib.hhe_multiply_plain(self.h, _ptr(ct), _ptr(plain), C.c_int(int(bcast)), _ptr(out), C.c_size_t(B)))
+
+    def apply_galois(self, ct, elt, out, B):
+        self._chk(self.lib.hhe_apply_galois(self.h, _ptr(ct), C.c_uint32(elt), _ptr(out), C.c_size_t(B)))
+
+    def rotate_rows(self, ct, step, out, B):
+        self._chk(self.lib.hhe_rotate_rows(self.h, _ptr(ct), C.c_int(step), _ptr(out), C.c_size_t(B)))
+
+    def rotate_columns(self, ct, out, B):
+        self._chk(self.lib.hhe_rotate_columns(self.h, _ptr(ct), _ptr(out), C.c_size_t(B)))
+
+    def multiply(self, a, b, out3, B):
+        self._chk(self.lib.hhe_multiply(self.h, _ptr(a), _ptr(b), _ptr(out3), C.c_size_t(B)))
+
+    def relinearize(self, a3, out, B):
+        self._chk(self.lib.hhe_relinearize(self.h, _ptr(a3), _ptr(out), C.c_size_t(B)))
+
+    # ---- hot path ----
+    def transcipher(self, enc_key, cw, ncw, block_index, out, use_bsgs=False):
+        """cw: host uint64 [B][128]; ncw [B]; block_index [B]; enc_key/out device."""
+        cw = np.ascontiguousarray(cw, dtype=np.uint64)
+        B = cw.shape[0]
+        assert cw.shape == (B, PASTA_T)
+        ncw = np.ascontiguousarray(ncw, dtype=np.uint32)
+        bi = np.ascontiguousarray(block_index, dtype=np.uint64)
+        assert ncw.shape == (B,) and bi.shape == (B,)
+        self._chk(self.lib.hhe_pasta3_transcipher(self.h, _ptr(enc_key), _ptr(cw), _ptr(ncw), _ptr(bi), C.c_size_t(B),
+                                                  C.c_int(int(use_bsgs)), _ptr(out)))
+
+    def clear_block_cache(self):
+        self.lib.hhe_pasta3_clear_block_cache(self.h)
+
+    def mask(self, ct, mask_vals, out, B):
+        mv = np.ascontiguousarray(mask_vals, dtype=np.uint64)
+        self._chk(self.lib.hhe_mask(self.h, _ptr(ct), _ptr(mv), C.c_size_t(len(mv)), _ptr(out), C.c_size_t(B)))
+
+    def flatten(self, blocks, nblocks, out, S):
+        self._chk(self.lib.hhe_flatten(self.h, _ptr(blocks), C.c_size_t(nblocks), _ptr(out), C.c_size_t(S)))
+
+    def fc_row(self, vi, w, W, n_inputs, out, B):
+        self._chk(self.lib.hhe_fc_row(self.h, _ptr(vi), _ptr(w), C.c_size_t(W), C.c_size_t(n_inputs), _ptr(out), C.c_size_t(B)))
+
+
+def block_randomness(t, block_index, lib=None):
+    lib = lib or load_library()
+    mats = np.zeros((4, 2, PASTA_T, PASTA_T), np.uint64)
+    rcs = np.zeros((4, 2, PASTA_T), np.uint64)
+    rc = lib.hhe_pasta3_block_randomness(C.c_uint64(t), C.c_uint64(block_index), _ptr(mats), _ptr(rcs))
+    if rc:
+        raise HheError(rc, lib.hhe_last_error().decode())
+    return mats, rcs

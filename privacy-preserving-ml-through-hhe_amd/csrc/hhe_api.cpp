@@ -1,0 +1,491 @@
+// hhe_api.cpp -- C ABI of libhhe_gfx950.so: batched BFV evaluator ops on device buffers
+// and the PASTA-3 transciphering / FC schedules built from them.  Host code only decides
+// the op order (the reference's schedule, src/pasta/pasta_3_seal.cpp); all arithmetic runs
+// in the gfx950 kernels of hhe_kernels.hip.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include "hhe_internal.h"
+#include "../../include/hhe_gfx950.h"
+
+namespace {
+
+int fail(int code, const std::string &msg) { hhe_set_error(msg); return code; }
+int dev_fail(const char *where) { return fail(HHE_ERR_DEVICE, std::string(where) + ": " + rt_last_error()); }
+
+int need(hhe_ctx *c, size_t B)
+{
+    if (!c || B == 0) return fail(HHE_ERR_INVALID, "null context or empty batch");
+    if (B > c->cap) {
+        int rc = hhe_ctx_reserve(c, B);
+        if (rc) return rc;
+    }
+    return HHE_OK;
+}
+
+NttArgs ntt_args(const hhe_ctx *c, const u64 *src, u64 *dst, size_t count, int mod_base, int mod_cycle)
+{
+    NttArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = src; a.dst = dst; a.mods = c->d_mods; a.logn = c->logn; a.count = (int)count;
+    a.mod_base = mod_base; a.mod_cycle = mod_cycle; a.src_div = 1; a.t = c->t;
+    a.load_op = LOAD_PLAIN; a.store_op = STORE_PLAIN; a.mul_cycle = 1; a.mul_item_polys = 1;
+    return a;
+}
+void op_ntt(hhe_ctx *c, u64 *polys, size_t count, int mod_base, int mod_cycle, bool inverse, int store_op = STORE_PLAIN)
+{
+    NttArgs a = ntt_args(c, polys, polys, count, mod_base, mod_cycle);
+    a.store_op = store_op;
+    k_ntt(a, inverse, c->stream);
+}
+void op_elt(hhe_ctx *c, int op, const u64 *x, const u64 *y, u64 *out, size_t count, int mod_base, int mod_cycle, int b_cycle = 0)
+{
+    EltArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a = x; a.b = y; a.out = out; a.mods = c->d_mods; a.logn = c->logn; a.count = (int)count;
+    a.mod_base = mod_base; a.mod_cycle = mod_cycle; a.b_cycle = b_cycle;
+    k_elt(a, op, c->stream);
+}
+// ct (+) ct over [B][size][L][N]
+void op_add(hhe_ctx *c, const u64 *x, const u64 *y, u64 *out, size_t B, int size) { op_elt(c, ELT_ADD, x, y, out, B * size * c->L, 0, c->L); }
+
+void op_add_plain(hhe_ctx *c, const u64 *ct, const u64 *plain, const u64 *const *plain_ptrs, size_t shift, bool bcast,
+                  bool subtract, bool negate, u64 *out, size_t B)
+{
+    AddPlainArgs a = c->apl;
+    a.ct = ct; a.plain = plain; a.plain_ptrs = plain_ptrs; a.plain_shift = shift; a.out = out; a.B = (int)B;
+    a.plain_bcast = bcast; a.subtract = subtract; a.negate_ct = negate;
+    k_add_plain(a, c->stream);
+}
+
+// BatchEncoder::encode: vals [B][stride] (first `count` used) -> plain [B][N]
+void op_encode(hhe_ctx *c, const u64 *vals, size_t B, int stride, int count, int second_off, u64 *plain)
+{
+    rt_memset(plain, 0, B * c->n * 8, c->stream);
+    EncodeArgs e;
+    memset(&e, 0, sizeof(e));
+    e.vals = vals; e.out = plain; e.slot_map = c->d_slot_map; e.logn = c->logn; e.B = (int)B;
+    e.stride = stride; e.count = count; e.second_off = second_off; e.t = c->t;
+    k_encode_scatter(e, c->stream);
+    op_ntt(c, plain, B, c->mod_t, 1, true);
+}
+
+// plain [P][N] (coefficients mod t) -> lifted NTT form [P][L][N]   
+void op_lift_ntt(hhe_ctx *c, const u64 *plain, size_t P, u64 *out)
+{
+    NttArgs a = ntt_args(c, plain, out, P * c->L, 0, c->L);
+    a.src_div = c->L; a.load_op = LOAD_LIFT;
+    k_ntt(a, false, c->stream);
+}
+
+// out = INTT(NTT(ct) * D) with D an NTT-form lifted plaintext: shared [L][N] (ptrs null) or per item
+void op_multiply_plain_ntt(hhe_ctx *c, const u64 *ct, const u64 *D, const u64 *const *D_ptrs, size_t shift, u64 *out, size_t B)
+{
+    NttArgs a = ntt_args(c, ct, out, B * 2 * c->L, 0, c->L);
+    a.store_op = STORE_MUL; a.mul = D; a.mul_ptrs = D_ptrs; a.mul_shift = shift; a.mul_cycle = c->L; a.mul_item_polys = 2 * c->L;
+    k_ntt(a, false, c->stream);
+    op_ntt(c, out, B * 2 * c->L, 0, c->L, true);
+}
+
+// Evaluator::switch_key_inplace core.  d: item b at d + b*d_stride, [L][N] coefficient form.
+// out[b] = (base ? base polys selected by mask : 0) + key-switched pair.
+void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, const u64 *base, size_t base_stride,
+                   int base_mask, u64 *out, size_t B)
+{
+    const int L = c->L, K = c->K;
+    NttArgs a = ntt_args(c, d, c->ws_T, B * L * K, 0, K);
+    a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = d_stride; a.load_op = LOAD_DIGIT;
+    k_ntt(a, false, c->stream);
+    KsMacArgs m;
+    memset(&m, 0, sizeof(m));
+    m.T = c->ws_T; m.key = key; m.S = c->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
+    k_ks_mac(m, c->stream);
+    op_ntt(c, c->ws_S, B * 2 * K, 0, K, true);
+    KsFinishArgs f = c->ksf;
+    f.S = c->ws_S; f.base = base; f.base_item_stride = base_stride; f.base_mask = base ? base_mask : 0; f.out = out; f.B = (int)B;
+    k_ks_finish(f, c->stream);
+}
+
+int op_apply_galois(hhe_ctx *c, const u64 *ct, u32 elt, u64 *out, size_t B)
+{
+    auto it = c->d_gk.find(elt);
+    if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    const int L = c->L;
+    const size_t n = c->n;
+    GaloisArgs g;
+    memset(&g, 0, sizeof(g));
+    g.mods = c->d_mods; g.logn = c->logn; g.count = (int)(B * L); g.L = L;
+    g.einv = (u32)nt_invmod(elt, 2 * n);
+    const u64 *src = ct;
+    if (ct == out) {  // gather cannot run in place
+        rt_d2d(c->ws_ct[3], ct, B * c->ct_words() * 8, c->stream);
+        src = c->ws_ct[3];
+    }
+    // c0' = galois(c0) -> out poly 0 ; d = galois(c1) -> ws_d
+    g.in = src; g.in_item_stride = 2 * L * n; g.out = out; g.out_item_stride = 2 * L * n;
+    k_galois(g, c->stream);
+    g.in = src + L * n; g.out = c->ws_d; g.out_item_stride = L * n;
+    k_galois(g, c->stream);
+    op_switch_key(c, c->ws_d, L * n, it->second, out, 2 * L * n, 1, out, B);
+    return HHE_OK;
+}
+
+// Evaluator::rotate_internal (seal/evaluator.h:1234)
+int op_rotate_rows(hhe_ctx *c, const u64 *ct, int step, u64 *out, size_t B)
+{
+    if (step == 0) {
+        if (ct != out) rt_d2d(out, ct, B * c->ct_words() * 8, c->stream);
+        return HHE_OK;
+    }
+    const u32 elt = galois_elt_from_step(c, step);
+    if (!elt) return fail(HHE_ERR_INVALID, "step count too large");
+    if (c->d_gk.count(elt)) return op_apply_galois(c, ct, elt, out, B);
+    const std::vector<int> terms = nt_naf(step);
+    if (terms.size() == 1) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    const u64 *cur = ct;
+    for (int term : terms) {
+        if ((size_t)std::abs(term) == c->n / 2) continue;
+        int rc = op_rotate_rows(c, cur, term, out, B);
+        if (rc) return rc;
+        cur = out;
+    }
+    if (cur == ct && ct != out) rt_d2d(out, ct, B * c->ct_words() * 8, c->stream);
+    return HHE_OK;
+}
+
+// Evaluator::bfv_multiply (BEHZ): a, b [B][2][L][N] -> out3 [B][3][L][N]
+void op_multiply(hhe_ctx *c, const u64 *x, const u64 *y, u64 *out3, size_t B)
+{
+    const int L = c->L, K = c->K;
+    auto extend = [&](const u64 *in, u64 *oq, u64 *ob) {
+        BehzExtendArgs e;
+        memset(&e, 0, sizeof(e));
+        e.x = in; e.xb = ob; e.mods = c->d_mods; e.bz = c->d_behz; e.logn = c->logn; e.P = (int)(B * 2); e.L = L; e.K = K;
+        k_behz_extend(e, c->stream);
+        op_ntt(c, ob, B * 2 * (L + 1), K, L + 1, false);
+        NttArgs a = ntt_args(c, in, oq, B * 2 * L, 0, L);
+        k_ntt(a, false, c->stream);
+    };
+    extend(x, c->bz_aq, c->bz_ab);
+    const u64 *bq = c->bz_aq, *bb = c->bz_ab;
+    if (y != x) { extend(y, c->bz_bq, c->bz_bb); bq = c->bz_bq; bb = c->bz_bb; }
+    TensorArgs t;
+    memset(&t, 0, sizeof(t));
+    t.mods = c->d_mods; t.logn = c->logn; t.B = (int)B;
+    t.a = c->bz_aq; t.b = bq; t.d = c->bz_dq; t.limbs = L; t.mod_base = 0;
+    k_tensor(t, c->stream);
+    t.a = c->bz_ab; t.b = bb; t.d = c->bz_db; t.limbs = L + 1; t.mod_base = K;
+    k_tensor(t, c->stream);
+    op_ntt(c, c->bz_dq, B * 3 * L, 0, L, true, STORE_SCALE_T);
+    op_ntt(c, c->bz_db, B * 3 * (L + 1), K, L + 1, true, STORE_SCALE_T);
+    BehzFloorArgs f;
+    memset(&f, 0, sizeof(f));
+    f.dq = c->bz_dq; f.db = c->bz_db; f.out = out3; f.mods = c->d_mods; f.bz = c->d_behz; f.logn = c->logn;
+    f.P = (int)(B * 3); f.L = L; f.K = K;
+    k_behz_floor(f, c->stream);
+}
+
+int op_relinearize(hhe_ctx *c, const u64 *a3, u64 *out, size_t B)
+{
+    if (!c->d_rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
+    const size_t ln = (size_t)c->L * c->n;
+    op_switch_key(c, a3 + 2 * ln, 3 * ln, c->d_rk, a3, 3 * ln, 3, out, B);
+    return HHE_OK;
+}
+
+// ------------------------------------------------------------------ PASTA public tables
+int ensure_feistel_mask(hhe_ctx *c)
+{
+    if (c->d_feistel_mask) return HHE_OK;
+    const size_t n = c->n, half = n / 2;
+    // mask_vec: ones on [1,128) and [N/2+1, N/2+128) (pasta_3_seal.cpp:230-235)
+    std::vector<u64> vals(2 * PASTA_T, 1);
+    vals[0] = 0; vals[PASTA_T] = 0;
+    u64 *dv = (u64 *)rt_malloc(vals.size() * 8), *pl = (u64 *)rt_malloc(n * 8);
+    c->d_feistel_mask = (u64 *)rt_malloc((size_t)c->L * n * 8);
+    if (!dv || !pl || !c->d_feistel_mask) return dev_fail("feistel mask alloc");
+    rt_h2d(dv, vals.data(), vals.size() * 8, c->stream);
+    op_encode(c, dv, 1, 2 * PASTA_T, PASTA_T, (int)half, pl);
+    op_lift_ntt(c, pl, 1, c->d_feistel_mask);
+    if (rt_sync(c->stream)) return dev_fail("feistel mask");
+    rt_free(dv); rt_free(pl);
+    return HHE_OK;
+}
+
+int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
+{
+    auto it = c->blocks.find(block);
+    if (it != c->blocks.end()) { *out = &it->second; return HHE_OK; }
+    const size_t n = c->n, half = n / 2;
+    const int L = c->L;
+    const size_t ndiag = (size_t)(PASTA_R + 1) * PASTA_T;
+    std::vector<u64> mats((size_t)(PASTA_R + 1) * 2 * PASTA_T * PASTA_T), rcs((size_t)(PASTA_R + 1) * 2 * PASTA_T);
+    pasta3_block_randomness(c->t, PASTA_NONCE, block, mats.data(), rcs.data());
+    BlockTables bt;
+    u64 *d_mats = (u64 *)rt_malloc(mats.size() * 8), *d_rcs = (u64 *)rt_malloc(rcs.size() * 8);
+    u64 *slots = (u64 *)rt_malloc(ndiag * n * 8);
+    bt.diag = (u64 *)rt_malloc(ndiag * L * n * 8);
+    bt.rc = (u64 *)rt_malloc((size_t)(PASTA_R + 1) * n * 8);
+    if (!d_mats || !d_rcs || !slots || !bt.diag || !bt.rc) return dev_fail("block table alloc");
+    rt_h2d(d_mats, mats.data(), mats.size() * 8, c->stream);
+    rt_h2d(d_rcs, rcs.data(), rcs.size() * 8, c->stream);
+    // 128 diagonals per affine layer -> slot image -> INTT mod t (= batch encode) -> lift + NTT per limb
+    rt_memset(slots, 0, ndiag * n * 8, c->stream);
+    DiagArgs d;
+    memset(&d, 0, sizeof(d));
+    d.mats = d_mats; d.out = slots; d.slot_map = c->d_slot_map; d.logn = c->logn;
+    k_diag(d, c->stream);
+    op_ntt(c, slots, ndiag, c->mod_t, 1, true);
+    op_lift_ntt(c, slots, ndiag, bt.diag);
+    // round constants: rc1 -> slots [0,128), rc2 -> slots [N/2, N/2+128) (pasta_3_plain.cpp:286-295)
+    op_encode(c, d_rcs, PASTA_R + 1, 2 * PASTA_T, PASTA_T, (int)half, bt.rc);
+    if (rt_sync(c->stream)) return dev_fail("block tables");
+    rt_free(d_mats); rt_free(d_rcs); rt_free(slots);
+    auto ins = c->blocks.emplace(block, bt);
+    *out = &ins.first->second;
+    return HHE_OK;
+}
+
+// PASTA_SEAL::diagonal (pasta_3_seal.cpp:370-413) for affine layer `layer`, state in ws_ct[0].
+// The 128 products are accumulated in the NTT domain and inverse-transformed once, which
+// yields the same words as SEAL's multiply_plain + add_inplace chain.
+int matmul_diagonal(hhe_ctx *c, int layer, const u64 *const *d_diag_ptrs, size_t B)
+{
+    const int L = c->L;
+    const size_t n = c->n;
+    u64 *state = c->ws_ct[0], *acc = c->ws_ct[1], *scratch = c->ws_ct[2];
+    if (n / 2 != PASTA_T) {
+        int rc = op_rotate_rows(c, state, PASTA_T, scratch, B);
+        if (rc) return rc;
+        op_add(c, state, scratch, state, B, 2);
+    }
+    rt_memset(acc, 0, B * c->ct_words() * 8, c->stream);
+    for (int i = 0; i < PASTA_T; ++i) {
+        if (i) {
+            int rc = op_rotate_rows(c, state, -1, state, B);
+            if (rc) return rc;
+        }
+        NttArgs a = ntt_args(c, state, scratch, B * 2 * L, 0, L);
+        a.store_op = STORE_MAC; a.mul_ptrs = d_diag_ptrs; a.mul_shift = ((size_t)layer * PASTA_T + i) * L * n;
+        a.mul_cycle = L; a.mul_item_polys = 2 * L; a.acc = acc;
+        k_ntt(a, false, c->stream);
+    }
+    op_ntt(c, acc, B * 2 * L, 0, L, true);
+    rt_d2d(state, acc, B * c->ct_words() * 8, c->stream);
+    return HHE_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" int hhe_ntt(hhe_ctx *c, uint64_t *polys, size_t count, int mod_base, int mod_cycle, int inverse)
+{
+    if (!c || !polys || mod_cycle < 1 || mod_base < 0 || mod_base + mod_cycle > c->nmod) return fail(HHE_ERR_INVALID, "hhe_ntt: bad arguments");
+    op_ntt(c, polys, count, mod_base, mod_cycle, inverse != 0);
+    return HHE_OK;
+}
+extern "C" int hhe_encode(hhe_ctx *c, const uint64_t *vals, size_t B, size_t count, uint64_t *plain)
+{
+    if (!c || !vals || !plain || count > c->n) return fail(HHE_ERR_INVALID, "hhe_encode: bad arguments");
+    op_encode(c, vals, B, (int)count, (int)count, -1, plain);
+    return HHE_OK;
+}
+extern "C" int hhe_add(hhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t B, int size)
+{
+    if (!c || !a || !b || !out) return fail(HHE_ERR_INVALID, "hhe_add: bad arguments");
+    op_add(c, a, b, out, B, size);
+    return HHE_OK;
+}
+extern "C" int hhe_negate(hhe_ctx *c, const uint64_t *a, uint64_t *out, size_t B, int size)
+{
+    if (!c || !a || !out) return fail(HHE_ERR_INVALID, "hhe_negate: bad arguments");
+    op_elt(c, ELT_NEG, a, nullptr, out, B * size * c->L, 0, c->L);
+    return HHE_OK;
+}
+extern "C" int hhe_add_plain(hhe_ctx *c, const uint64_t *ct, const uint64_t *plain, int bcast, int subtract, uint64_t *out, size_t B)
+{
+    if (!c || !ct || !plain || !out) return fail(HHE_ERR_INVALID, "hhe_add_plain: bad arguments");
+    op_add_plain(c, ct, plain, nullptr, 0, bcast != 0, subtract != 0, false, out, B);
+    return HHE_OK;
+}
+extern "C" int hhe_multiply_plain(hhe_ctx *c, const uint64_t *ct, const uint64_t *plain, int bcast, uint64_t *out, size_t B)
+{
+    if (!c || !ct || !plain || !out) return fail(HHE_ERR_INVALID, "hhe_multiply_plain: bad arguments");
+    int rc = need(c, B);
+    if (rc) return rc;
+    const size_t P = bcast ? 1 : B;
+    u64 *D = c->ws_ct3;  // [P][L][N] fits in [B][3][L][N]
+    op_lift_ntt(c, plain, P, D);
+    if (bcast) op_multiply_plain_ntt(c, ct, D, nullptr, 0, out, B);
+    else {
+        NttArgs a = ntt_args(c, ct, out, B * 2 * c->L, 0, c->L);
+        a.store_op = STORE_MUL;
+        // per-item multiplier: items laid [B][L][N]; reuse the pointer form with a flat table
+        std::vector<const u64 *> ptrs(B);
+        for (size_t b = 0; b < B; ++b) ptrs[b] = D + b * c->L * c->n;
+        const u64 **dp = (const u64 **)rt_malloc(B * sizeof(u64 *));
+        if (!dp) return dev_fail("hhe_multiply_plain");
+        rt_h2d(dp, ptrs.data(), B * sizeof(u64 *), c->stream);
+        a.mul_ptrs = dp; a.mul_cycle = c->L; a.mul_item_polys = 2 * c->L;
+        k_ntt(a, false, c->stream);
+        op_ntt(c, out, B * 2 * c->L, 0, c->L, true);
+        rt_sync(c->stream);
+        rt_free(dp);
+    }
+    return HHE_OK;
+}
+extern "C" int hhe_apply_galois(hhe_ctx *c, const uint64_t *ct, uint32_t elt, uint64_t *out, size_t B)
+{
+    int rc = need(c, B);
+    if (rc) return rc;
+    return op_apply_galois(c, ct, elt, out, B);
+}
+extern "C" int hhe_rotate_rows(hhe_ctx *c, const uint64_t *ct, int step, uint64_t *out, size_t B)
+{
+    int rc = need(c, B);
+    if (rc) return rc;
+    return op_rotate_rows(c, ct, step, out, B);
+}
+extern "C" int hhe_rotate_columns(hhe_ctx *c, const uint64_t *ct, uint64_t *out, size_t B)
+{
+    int rc = need(c, B);
+    if (rc) return rc;
+    return op_apply_galois(c, ct, (u32)(2 * c->n - 1), out, B);
+}
+extern "C" int hhe_multiply(hhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out3, size_t B)
+{
+    int rc = need(c, B);
+    if (rc) return rc;
+    op_multiply(c, a, b, out3, B);
+    return HHE_OK;
+}
+extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, size_t B)
+{
+    int rc = need(c, B);
+    if (rc) return rc;
+    return op_relinearize(c, a3, out, B);
+}
+
+extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *cw, const uint32_t *ncw,
+                                      const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
+{
+    if (!c || !enc_key || !cw || !ncw || !block_index || !out) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: null argument");
+    if (use_bsgs) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: babystep-giantstep variant not built yet");
+    const size_t n = c->n, half = n / 2;
+    const int L = c->L;
+    // pasta_3_seal.cpp:376-377
+    if ((size_t)PASTA_T * 2 != n && (size_t)PASTA_T * 4 > n) return fail(HHE_ERR_TOO_FEW_SLOTS, "too little slots for matmul implementation!");
+    if (!c->d_rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
+    for (int step : {-1, half != PASTA_T ? PASTA_T : -1, 0})
+        if (!c->d_gk.count(galois_elt_from_step(c, step))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    int rc = need(c, B);
+    if (rc) return rc;
+    if ((rc = ensure_feistel_mask(c))) return rc;
+    // per-item public tables
+    std::vector<const u64 *> diag_ptrs(B), rc_ptrs(B);
+    std::vector<u64> cwp(B * PASTA_T, 0);
+    for (size_t b = 0; b < B; ++b) {
+        if (ncw[b] > PASTA_T) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: more than 128 words in a block");
+        BlockTables *bt = nullptr;
+        if ((rc = ensure_block(c, block_index[b], &bt))) return rc;
+        diag_ptrs[b] = bt->diag; rc_ptrs[b] = bt->rc;
+        memcpy(&cwp[b * PASTA_T], cw + b * PASTA_T, ncw[b] * 8);
+    }
+    const u64 **d_ptrs = (const u64 **)rt_malloc(2 * B * sizeof(u64 *));
+    if (!d_ptrs) return dev_fail("hhe_pasta3_transcipher");
+    rt_h2d(d_ptrs, diag_ptrs.data(), B * sizeof(u64 *), c->stream);
+    rt_h2d(d_ptrs + B, rc_ptrs.data(), B * sizeof(u64 *), c->stream);
+    rt_h2d(c->ws_vals, cwp.data(), cwp.size() * 8, c->stream);
+
+    u64 *state = c->ws_ct[0], *tmp = c->ws_ct[1], *t3 = c->ws_ct3;
+    // state <- enc_ssk[0] for every item (pasta_3_seal.cpp:126)
+    op_elt(c, ELT_BCAST, nullptr, enc_key, state, B * 2 * L, 0, L, 2 * L);
+    for (int r = 0; r <= PASTA_R && !rc; ++r) {
+        if ((rc = matmul_diagonal(c, r, d_ptrs, B))) break;
+        // add_rc (:205-211)
+        op_add_plain(c, state, nullptr, d_ptrs + B, (size_t)r * n, false, false, false, state, B);
+        // mix (:417-423)
+        if ((rc = op_apply_galois(c, state, (u32)(2 * n - 1), tmp, B))) break;
+        op_add(c, tmp, state, tmp, B, 2);
+        op_add(c, state, tmp, state, B, 2);
+        if (r == PASTA_R) break;
+        if (r == PASTA_R - 1) {
+            // sbox_cube (:215-218): exponentiate_inplace(x,3) == relin(mul(relin(mul(x,x)), x))
+            op_multiply(c, state, state, t3, B);
+            if ((rc = op_relinearize(c, t3, tmp, B))) break;
+            op_multiply(c, tmp, state, t3, B);
+            if ((rc = op_relinearize(c, t3, state, B))) break;
+        } else {
+            // sbox_feistel (:222-247)
+            if ((rc = op_rotate_rows(c, state, -1, tmp, B))) break;
+            op_multiply_plain_ntt(c, tmp, c->d_feistel_mask, nullptr, 0, tmp, B);
+            op_multiply(c, tmp, tmp, t3, B);
+            if ((rc = op_relinearize(c, t3, tmp, B))) break;
+            op_add(c, state, tmp, state, B, 2);
+        }
+    }
+    if (!rc) {
+        // res = Enc(c_b) - KS : encode, negate, add_plain (:161-169)
+        op_encode(c, c->ws_vals, B, PASTA_T, PASTA_T, -1, c->ws_plain);
+        op_add_plain(c, state, c->ws_plain, nullptr, 0, false, false, true, out, B);
+    }
+    if (rt_sync(c->stream) && !rc) rc = dev_fail("hhe_pasta3_transcipher");
+    rt_free(d_ptrs);
+    return rc;
+}
+
+extern "C" int hhe_mask(hhe_ctx *c, const uint64_t *ct, const uint64_t *mask_vals, size_t count, uint64_t *out, size_t B)
+{
+    if (!c || !ct || !mask_vals || !out || count > c->n) return fail(HHE_ERR_INVALID, "hhe_mask: bad arguments");
+    int rc = need(c, B);
+    if (rc) return rc;
+    u64 *dv = (u64 *)rt_malloc(count * 8);
+    if (!dv) return dev_fail("hhe_mask");
+    rt_h2d(dv, mask_vals, count * 8, c->stream);
+    op_encode(c, dv, 1, (int)count, (int)count, -1, c->ws_plain);
+    u64 *D = c->ws_ct3;
+    op_lift_ntt(c, c->ws_plain, 1, D);
+    op_multiply_plain_ntt(c, ct, D, nullptr, 0, out, B);
+    if (rt_sync(c->stream)) rc = dev_fail("hhe_mask");
+    rt_free(dv);
+    return rc;
+}
+
+extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, uint64_t *out, size_t S)
+{
+    if (!c || !blocks || !out || nblocks == 0) return fail(HHE_ERR_INVALID, "hhe_flatten: bad arguments");
+    int rc = need(c, S);
+    if (rc) return rc;
+    const size_t ctw = c->ct_words();
+    // gather block i of every sample into a contiguous batch, rotate by -128*i, accumulate
+    EltArgs g;
+    auto gather = [&](size_t i, u64 *dst) {
+        for (size_t s = 0; s < S; ++s) rt_d2d(dst + s * ctw, blocks + (s * nblocks + i) * ctw, ctw * 8, c->stream);
+    };
+    (void)g;
+    gather(0, out);
+    for (size_t i = 1; i < nblocks; ++i) {
+        gather(i, c->ws_ct[0]);
+        if ((rc = op_rotate_rows(c, c->ws_ct[0], -(int)(i * PASTA_T), c->ws_ct[1], S))) return rc;
+        op_add(c, out, c->ws_ct[1], out, S, 2);
+    }
+    return HHE_OK;
+}
+
+extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, uint64_t *out, size_t B)
+{
+    if (!c || !vi || !w || !out || W == 0 || n_inputs == 0 || n_inputs > c->n / 2) return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
+    int rc = need(c, B);
+    if (rc) return rc;
+    const int L = c->L;
+    u64 *wb = c->ws_ct[0], *prod = c->ws_ct[1], *rot = c->ws_ct[2];
+    op_elt(c, ELT_BCAST, nullptr, w, wb, B * 2 * L, 0, L, (int)(W * 2 * L));
+    op_multiply(c, vi, wb, c->ws_ct3, B);                      // packed_enc_multiply
+    if ((rc = op_relinearize(c, c->ws_ct3, prod, B))) return rc;  // CSP.cpp:306
+    rt_d2d(out, prod, B * c->ct_words() * 8, c->stream);
+    for (size_t i = 1; i < n_inputs; ++i) {                    // encrypted_vec_sum (sealhelper.cpp:379-392)
+        if ((rc = op_rotate_rows(c, prod, -(int)i, rot, B))) return rc;
+        op_add(c, out, rot, out, B, 2);
+    }
+    return HHE_OK;
+}

@@ -1,0 +1,171 @@
+// hhe_common.h -- shared types for the gfx950 BFV/PASTA-3 kernels and their host driver.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HD __host__ __device__ __forceinline__
+#else
+#define HD inline
+#endif
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+constexpr int HHE_MAXL = 16;          // data-level RNS limbs supported
+constexpr int HHE_MAXK = HHE_MAXL + 1;
+constexpr int PASTA_T = 128;          // pasta_3_plain.h:18,32
+constexpr int PASTA_R = 3;            // pasta_3_plain.h:33
+constexpr u64 PASTA_NONCE = 123456789ULL;  // pasta_3_seal.cpp:47,115
+
+// One RNS modulus as the kernels see it.  Tables live in device memory.
+struct ModDev {
+    u64 q;
+    u64 r_lo, r_hi;        // floor(2^128 / q)
+    u64 ninv, ninv_s;      // N^-1 mod q and its Shoup quotient
+    u64 ninv_t, ninv_t_s;  // N^-1 * t mod q (INTT fused with the BEHZ "times t")
+    const u64 *w, *ws;     // psi^bitrev(k), Shoup quotients          [N]
+    const u64 *iw, *iws;   // inverse of the same entries             [N]
+};
+
+// Modulus indices inside ModDev[]: 0..K-1 coefficient primes (K-1 = special),
+// K..K+L Bsk = {B_0..B_{L-1}, m_sk}, K+L+1 = plain modulus t.
+
+enum NttLoadOp { LOAD_PLAIN = 0, LOAD_DIGIT = 1, LOAD_LIFT = 2 };
+enum NttStoreOp { STORE_PLAIN = 0, STORE_MUL = 1, STORE_SCALE_T = 2, STORE_MAC = 3 };
+
+struct NttArgs {
+    const u64 *src;
+    u64 *dst;
+    const ModDev *mods;
+    int logn;
+    int logm;       // log2 of this pass's sub-transform size
+    int logc;       // log2 lanes (independent sub-transforms) per tile
+    int count;      // polynomials in the batch
+    int mod_base, mod_cycle;  // modulus of poly p = mod_base + p % mod_cycle
+    // source poly of p: src + (p / src_item_polys) * src_item_stride + ((p % src_item_polys) / src_div) * N
+    int src_div;          // DIGIT: K, LIFT: L, else 1
+    int src_item_polys;   // polys of one batch item in p-space (0 => whole batch is one item)
+    size_t src_item_stride;  // words between items in src
+    int load_op, store_op;
+    u64 t;          // LIFT: plain modulus
+    // STORE_MUL / STORE_MAC multiplier (NTT form): (mul_ptrs ? mul_ptrs[p / mul_item_polys] : mul)
+    //   + mul_shift + (p % mul_cycle) * N
+    const u64 *mul;
+    const u64 *const *mul_ptrs;
+    size_t mul_shift;
+    int mul_cycle, mul_item_polys;
+    u64 *acc;       // STORE_MAC: acc[p][i] += NTT(x)[i] * mul
+};
+
+enum EltOp { ELT_ADD = 0, ELT_SUB = 1, ELT_NEG = 2, ELT_MUL = 3, ELT_MAC = 4, ELT_COPY = 5, ELT_BCAST = 6 };
+
+struct EltArgs {  // element-wise kernels over [count][N] polys, modulus = mod_base + p % mod_cycle
+    const u64 *a, *b;
+    u64 *out;
+    const ModDev *mods;
+    int logn, count, mod_base, mod_cycle;
+    int b_cycle;  // poly of b = p % b_cycle (broadcast over the batch), 0 => same index
+};
+
+struct GaloisArgs {  // out[p][k] = +-in[p][k * einv mod 2N]; poly p = (item b, limb j), p = b * L + j
+    const u64 *in;
+    u64 *out;
+    const ModDev *mods;
+    int logn, count, L;
+    size_t in_item_stride, out_item_stride;  // words between items
+    u32 einv;  // elt^-1 mod 2N
+};
+
+struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
+    const u64 *T;    // [B][L][K][N]
+    const u64 *key;  // [L][2][K][N]
+    u64 *S;          // [B][2][K][N]
+    const ModDev *mods;
+    int logn, B, L, K;
+};
+
+struct KsFinishArgs {  // SURVEY A.4 mod-down; S already INTT'd (coefficient form)
+    const u64 *S;     // [B][2][K][N]
+    const u64 *base;  // item b at base + b * base_item_stride, polys [2][L][N]; or null
+    size_t base_item_stride;
+    u64 *out;         // [B][2][L][N]
+    const ModDev *mods;
+    int logn, B, L, K;
+    int base_mask;    // bit k set => add base poly k
+    u64 half;                 // floor(q_sp/2)
+    u64 half_mod[HHE_MAXL];   // half mod q_j
+    u64 qsp_inv[HHE_MAXL];    // q_sp^-1 mod q_j
+    u64 qsp_inv_s[HHE_MAXL];
+};
+
+struct AddPlainArgs {
+    const u64 *ct;     // [B][2][L][N]
+    const u64 *plain;  // [B or 1][N] coefficients mod t
+    const u64 *const *plain_ptrs;  // if set: item b reads plain_ptrs[b] + plain_shift
+    size_t plain_shift;
+    u64 *out;
+    const ModDev *mods;
+    int logn, B, L;
+    int plain_bcast;   // 1: one plain for the whole batch
+    int negate_ct;     // 1: out = -ct (+/-) plain
+    int subtract;      // 1: sub_plain
+    u64 t, q_mod_t, thr;
+    u64 t_r_lo, t_r_hi;        // floor(2^128/t)
+    u64 delta[HHE_MAXL];
+};
+
+struct EncodeArgs {  // slot scatter; INTT mod t follows as an NTT launch
+    const u64 *vals;   // [B][stride]
+    u64 *out;          // [B][N]
+    const u32 *slot_map;
+    int logn, B, stride, count;  // count values per item placed at slots [0,count)
+    int second_off;    // >=0: values [count, 2*count) go to slots [second_off, second_off+count)
+    u64 t;
+};
+
+struct DiagArgs {  // PASTA_SEAL::diagonal preparation (pasta_3_seal.cpp:390-401) into slot order
+    const u64 *mats;   // [4][2][128][128]
+    u64 *out;          // [4*128][N]  (pre-INTT slot image)
+    const u32 *slot_map;
+    int logn;
+};
+
+struct BehzDev {  // SURVEY A.7 constants
+    int L;
+    u64 inv_punct_q[HHE_MAXL], inv_punct_q_s[HHE_MAXL];
+    u64 mt_mod_q[HHE_MAXL];                      // 2^32 mod q_i
+    u64 punct_q_bsk[HHE_MAXL][HHE_MAXL + 1];
+    u64 punct_q_mt[HHE_MAXL];
+    u64 neg_inv_q_mt;
+    u64 q_mod_bsk[HHE_MAXL + 1], inv_mt_bsk[HHE_MAXL + 1], inv_q_bsk[HHE_MAXL + 1];
+    u64 inv_punct_B[HHE_MAXL];
+    u64 punct_B_q[HHE_MAXL][HHE_MAXL];
+    u64 punct_B_msk[HHE_MAXL];
+    u64 inv_B_msk, msk;
+    u64 B_mod_q[HHE_MAXL], neg_B_mod_q[HHE_MAXL];
+};
+
+struct BehzExtendArgs {  // x [P][L][N] coeff -> xb [P][L+1][N] coeff (then NTT'd)
+    const u64 *x;
+    u64 *xb;
+    const ModDev *mods;
+    const BehzDev *bz;
+    int logn, P, L, K;
+};
+
+struct TensorArgs {  // d[b][0..2][j] from a[b][0..1][j], b[b][0..1][j]; NTT domain
+    const u64 *a, *b;
+    u64 *d;
+    const ModDev *mods;
+    int logn, B, limbs, mod_base;
+};
+
+struct BehzFloorArgs {  // (dq [P][L][N], db [P][L+1][N]) coeff, already *t -> out [P][L][N]
+    const u64 *dq, *db;
+    u64 *out;
+    const ModDev *mods;
+    const BehzDev *bz;
+    int logn, P, L, K;
+};

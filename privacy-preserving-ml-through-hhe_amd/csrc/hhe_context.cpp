@@ -1,0 +1,394 @@
+// hhe_context.cpp -- parameter derivation and device-resident tables for one BFV context.
+// Follows what SEAL 4.0.0's SEALContext computes for the same (N, coeff_modulus, t):
+// NTTTables (seal/util/ntt.h:69-183), BatchEncoder index map (seal/batchencoder.h),
+// RNSTool's BEHZ base (seal/util/rns.h:324-399), the BFV scaling-variant constants
+// (seal/context.h:350-401).  See SURVEY.md Appendix A for the restated arithmetic.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "hhe_internal.h"
+#include "../../include/hhe_gfx950.h"
+
+typedef unsigned __int128 u128;
+
+static thread_local std::string g_err;
+void hhe_set_error(const std::string &msg) { g_err = msg; }
+extern "C" const char *hhe_last_error(void) { return g_err.c_str(); }
+extern "C" const char *hhe_backend(void) { return rt_backend_name(); }
+
+// ------------------------------------------------------------------ number theory
+u64 nt_mulmod(u64 a, u64 b, u64 m) { return (u64)((u128)a * b % m); }
+u64 nt_powmod(u64 a, u64 e, u64 m)
+{
+    u64 r = 1 % m, x = a % m;
+    for (; e; e >>= 1, x = nt_mulmod(x, x, m))
+        if (e & 1) r = nt_mulmod(r, x, m);
+    return r;
+}
+u64 nt_invmod(u64 a, u64 m)
+{
+    __int128 r0 = m, r1 = a % m, s0 = 0, s1 = 1;
+    while (r1 != 0) {
+        __int128 k = r0 / r1;
+        __int128 r2 = r0 - k * r1; r0 = r1; r1 = r2;
+        __int128 s2 = s0 - k * s1; s0 = s1; s1 = s2;
+    }
+    return (u64)(s0 < 0 ? s0 + m : s0);
+}
+bool nt_is_prime(u64 v)
+{
+    if (v < 2) return false;
+    for (u64 p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        if (v == p) return true;
+        if (v % p == 0) return false;
+    }
+    u64 d = v - 1;
+    int s = 0;
+    while ((d & 1) == 0) { d >>= 1; ++s; }
+    // bases 2..37 are a deterministic Miller-Rabin certificate below 2^64
+    for (u64 base : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        u64 x = nt_powmod(base, d, v);
+        if (x == 1 || x == v - 1) continue;
+        bool witness = true;
+        for (int i = 1; i < s && witness; ++i) {
+            x = nt_mulmod(x, x, v);
+            if (x == v - 1) witness = false;
+        }
+        if (witness) return false;
+    }
+    return true;
+}
+// util::get_primes (seal/util/numth.h:138-139): descending from the top of the bit size
+bool nt_get_primes(u64 factor, int bits, size_t count, std::vector<u64> &out)
+{
+    out.clear();
+    u64 cand = (((u64)1 << bits) - 1) / factor * factor + 1;
+    const u64 floor_v = (u64)1 << (bits - 1);
+    for (; out.size() < count && cand > floor_v; cand -= factor)
+        if (nt_is_prime(cand)) out.push_back(cand);
+    return out.size() == count;
+}
+// util::try_minimal_primitive_root (seal/util/numth.h:155-157)
+u64 nt_minimal_primitive_root(u64 degree, u64 q)
+{
+    const u64 cofactor = (q - 1) / degree;
+    u64 root = 0;
+    for (u64 g = 2; g < q; ++g) {
+        root = nt_powmod(g, cofactor, q);
+        if (nt_powmod(root, degree / 2, q) == q - 1) break;
+    }
+    // all primitive roots are the odd powers of one of them
+    const u64 step = nt_mulmod(root, root, q);
+    u64 best = root, cur = root;
+    for (u64 i = 1; i < degree / 2; ++i) {
+        cur = nt_mulmod(cur, step, q);
+        if (cur < best) best = cur;
+    }
+    return best;
+}
+// util::naf (seal/util/numth.h:22-42)
+std::vector<int> nt_naf(int value)
+{
+    std::vector<int> terms;
+    const bool neg = value < 0;
+    unsigned v = (unsigned)std::abs(value);
+    for (int bit = 0; v; ++bit) {
+        int z = (v & 1u) ? 2 - (int)(v & 3u) : 0;
+        v = (unsigned)((int)v - z) >> 1;
+        if (z) terms.push_back((neg ? -z : z) * (1 << bit));
+    }
+    return terms;
+}
+// GaloisTool::get_elt_from_step (seal/util/galois.h:124)
+u32 galois_elt_from_step(const hhe_ctx *c, int step)
+{
+    const u64 m = 2 * (u64)c->n;
+    if (step == 0) return (u32)(m - 1);
+    const u64 mag = (u64)std::abs(step);
+    if (mag >= c->n / 2) return 0;
+    const u64 e = step > 0 ? mag : c->n / 2 - mag;
+    return (u32)nt_powmod(3, e, m);
+}
+
+static u64 bit_reverse(u64 v, int bits)
+{
+    u64 r = 0;
+    for (int i = 0; i < bits; ++i, v >>= 1) r = (r << 1) | (v & 1);
+    return r;
+}
+static u64 shoup_quot(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+static u64 product_mod(const std::vector<u64> &v, int skip, u64 m)
+{
+    u64 r = 1 % m;
+    for (int i = 0; i < (int)v.size(); ++i)
+        if (i != skip) r = nt_mulmod(r, v[i] % m, m);
+    return r;
+}
+
+// ------------------------------------------------------------------ context
+static void fill_mod(ModDev &md, u64 q, int logn, u64 t, bool with_tables, u64 *host_tab, const u64 *dev_tab, u64 *root_out)
+{
+    memset(&md, 0, sizeof(md));
+    md.q = q;
+    const u128 two64 = (u128)1 << 64;
+    md.r_hi = (u64)(two64 / q);
+    md.r_lo = (u64)(((two64 % q) << 64) / q);
+    if (!with_tables) return;
+    const size_t n = (size_t)1 << logn;
+    const u64 psi = nt_minimal_primitive_root(2 * n, q), ipsi = nt_invmod(psi, q);
+    if (root_out) *root_out = psi;
+    u64 *w = host_tab, *ws = host_tab + n, *iw = host_tab + 2 * n, *iws = host_tab + 3 * n;
+    u64 pw = 1, ipw = 1;
+    for (size_t k = 0; k < n; ++k) {
+        const size_t r = bit_reverse(k, logn);
+        w[r] = pw; ws[r] = shoup_quot(pw, q);
+        iw[r] = ipw; iws[r] = shoup_quot(ipw, q);
+        pw = nt_mulmod(pw, psi, q);
+        ipw = nt_mulmod(ipw, ipsi, q);
+    }
+    md.ninv = nt_invmod(n % q, q);
+    md.ninv_s = shoup_quot(md.ninv, q);
+    md.ninv_t = nt_mulmod(md.ninv, t % q, q);
+    md.ninv_t_s = shoup_quot(md.ninv_t, q);
+    md.w = dev_tab; md.ws = dev_tab + n; md.iw = dev_tab + 2 * n; md.iws = dev_tab + 3 * n;
+}
+
+extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, int device, hhe_ctx **out)
+{
+    if (!out || !q || logn < 10 || logn > 16 || K < 2 || K > HHE_MAXK) {
+        hhe_set_error("hhe_ctx_create: invalid arguments (need 10 <= logn <= 16, 2 <= K <= 17)");
+        return HHE_ERR_INVALID;
+    }
+    const size_t n = (size_t)1 << logn;
+    for (int i = 0; i < K; ++i)
+        if (q[i] >> 61 || (q[i] - 1) % (2 * n) != 0 || !nt_is_prime(q[i])) {
+            hhe_set_error("hhe_ctx_create: coeff modulus must be primes < 2^61 congruent to 1 mod 2N");
+            return HHE_ERR_INVALID;
+        }
+    if (t >> 61 || (t - 1) % (2 * n) != 0 || !nt_is_prime(t)) {
+        hhe_set_error("hhe_ctx_create: plain modulus must be a prime congruent to 1 mod 2N (batching)");
+        return HHE_ERR_INVALID;
+    }
+    if (rt_set_device(device)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
+    hhe_ctx *c = new hhe_ctx();
+    c->logn = logn; c->n = n; c->K = K; c->L = K - 1; c->t = t; c->device = device;
+    c->q.assign(q, q + K);
+    const int L = c->L;
+    // BEHZ base (seal/util/rns.h): get_primes(2N, 61, L+2) = m_sk, gamma, B_0..B_{L-1}
+    std::vector<u64> aux;
+    if (!nt_get_primes(2 * n, 61, (size_t)L + 2, aux)) { delete c; hhe_set_error("no BEHZ primes"); return HHE_ERR_INVALID; }
+    c->gamma = aux[1];
+    c->bsk.assign(aux.begin() + 2, aux.end());
+    c->bsk.push_back(aux[0]);
+    c->nmod = K + (L + 1) + 1;
+    c->mod_t = K + L + 1;
+
+    std::vector<u64> allq(c->q);
+    allq.insert(allq.end(), c->bsk.begin(), c->bsk.end());
+    allq.push_back(t);
+    std::vector<ModDev> mods(c->nmod);
+    std::vector<u64> host_tab((size_t)c->nmod * 4 * n);
+    c->d_tables = (u64 *)rt_malloc(host_tab.size() * 8);
+    c->d_mods = (ModDev *)rt_malloc(sizeof(ModDev) * c->nmod);
+    c->roots.resize(K);
+    for (int i = 0; i < c->nmod; ++i)
+        fill_mod(mods[i], allq[i], logn, t, true, host_tab.data() + (size_t)i * 4 * n, c->d_tables + (size_t)i * 4 * n,
+                 i < K ? &c->roots[i] : nullptr);
+    // BatchEncoder matrix_reps_index_map
+    c->slot_map.resize(n);
+    {
+        const u64 m = 2 * n;
+        u64 pos = 1;
+        for (size_t i = 0; i < n / 2; ++i) {
+            c->slot_map[i] = (u32)bit_reverse((pos - 1) >> 1, logn);
+            c->slot_map[n / 2 + i] = (u32)bit_reverse((m - pos - 1) >> 1, logn);
+            pos = pos * 3 % m;
+        }
+    }
+    c->d_slot_map = (u32 *)rt_malloc(4 * n);
+
+    std::vector<u64> dq(c->q.begin(), c->q.begin() + L), Bq(c->bsk.begin(), c->bsk.begin() + L);
+    const u64 msk = c->bsk[L], MT = (u64)1 << 32;
+    // add_plain scaling variant
+    AddPlainArgs &ap = c->apl;
+    memset(&ap, 0, sizeof(ap));
+    ap.t = t; ap.q_mod_t = product_mod(dq, -1, t); ap.thr = (t + 1) >> 1;
+    {
+        const u128 two64 = (u128)1 << 64;
+        ap.t_r_hi = (u64)(two64 / t);
+        ap.t_r_lo = (u64)(((two64 % t) << 64) / t);
+    }
+    for (int j = 0; j < L; ++j) {
+        // floor(Q/t) mod q_j = -(Q mod t) * t^-1 mod q_j  (Q = 0 mod q_j)
+        const u64 v = nt_mulmod(ap.q_mod_t % dq[j], nt_invmod(t % dq[j], dq[j]), dq[j]);
+        ap.delta[j] = v ? dq[j] - v : 0;
+    }
+    // key-switch mod-down
+    KsFinishArgs &kf = c->ksf;
+    memset(&kf, 0, sizeof(kf));
+    const u64 qsp = c->q[K - 1];
+    kf.half = qsp >> 1;
+    for (int j = 0; j < L; ++j) {
+        kf.half_mod[j] = kf.half % dq[j];
+        kf.qsp_inv[j] = nt_invmod(qsp % dq[j], dq[j]);
+        kf.qsp_inv_s[j] = shoup_quot(kf.qsp_inv[j], dq[j]);
+    }
+    // BEHZ constants
+    BehzDev bz;
+    memset(&bz, 0, sizeof(bz));
+    bz.L = L; bz.msk = msk;
+    for (int i = 0; i < L; ++i) {
+        bz.inv_punct_q[i] = nt_invmod(product_mod(dq, i, dq[i]), dq[i]);
+        bz.inv_punct_q_s[i] = shoup_quot(bz.inv_punct_q[i], dq[i]);
+        bz.mt_mod_q[i] = MT % dq[i];
+        for (int p = 0; p <= L; ++p) bz.punct_q_bsk[i][p] = product_mod(dq, i, c->bsk[p]);
+        bz.punct_q_mt[i] = product_mod(dq, i, MT);
+        bz.inv_punct_B[i] = nt_invmod(product_mod(Bq, i, Bq[i]), Bq[i]);
+        for (int j = 0; j < L; ++j) bz.punct_B_q[i][j] = product_mod(Bq, i, dq[j]);
+        bz.punct_B_msk[i] = product_mod(Bq, i, msk);
+        bz.B_mod_q[i] = product_mod(Bq, -1, dq[i]);
+        bz.neg_B_mod_q[i] = dq[i] - bz.B_mod_q[i];
+    }
+    bz.neg_inv_q_mt = (MT - nt_invmod(product_mod(dq, -1, MT), MT)) & (MT - 1);
+    for (int p = 0; p <= L; ++p) {
+        const u64 P = c->bsk[p];
+        bz.q_mod_bsk[p] = product_mod(dq, -1, P);
+        bz.inv_mt_bsk[p] = nt_invmod(MT % P, P);
+        bz.inv_q_bsk[p] = nt_invmod(bz.q_mod_bsk[p], P);
+    }
+    bz.inv_B_msk = nt_invmod(product_mod(Bq, -1, msk), msk);
+    c->d_behz = (BehzDev *)rt_malloc(sizeof(BehzDev));
+
+    if (!c->d_tables || !c->d_mods || !c->d_slot_map || !c->d_behz ||
+        rt_h2d(c->d_tables, host_tab.data(), host_tab.size() * 8, nullptr) ||
+        rt_h2d(c->d_mods, mods.data(), sizeof(ModDev) * c->nmod, nullptr) ||
+        rt_h2d(c->d_slot_map, c->slot_map.data(), 4 * n, nullptr) ||
+        rt_h2d(c->d_behz, &bz, sizeof(bz), nullptr) || rt_sync(nullptr)) {
+        hhe_set_error(std::string("hhe_ctx_create: device setup failed: ") + rt_last_error());
+        hhe_ctx_destroy(c);
+        return HHE_ERR_DEVICE;
+    }
+    kf.mods = c->d_mods; kf.logn = logn; kf.L = L; kf.K = K;
+    ap.mods = c->d_mods; ap.logn = logn; ap.L = L;
+    *out = c;
+    return HHE_OK;
+}
+
+static void free_ws(hhe_ctx *c)
+{
+    rt_free(c->ws_T); rt_free(c->ws_S); rt_free(c->ws_d); rt_free(c->ws_ct3); rt_free(c->ws_plain); rt_free(c->ws_vals);
+    for (auto &p : c->ws_ct) { rt_free(p); p = nullptr; }
+    rt_free(c->bz_aq); rt_free(c->bz_bq); rt_free(c->bz_ab); rt_free(c->bz_bb); rt_free(c->bz_dq); rt_free(c->bz_db);
+    c->ws_T = c->ws_S = c->ws_d = c->ws_ct3 = c->ws_plain = c->ws_vals = nullptr;
+    c->bz_aq = c->bz_bq = c->bz_ab = c->bz_bb = c->bz_dq = c->bz_db = nullptr;
+    c->cap = 0;
+}
+
+extern "C" void hhe_pasta3_clear_block_cache(hhe_ctx *c)
+{
+    if (!c) return;
+    rt_sync(c->stream);
+    for (auto &kv : c->blocks) { rt_free(kv.second.diag); rt_free(kv.second.rc); rt_free(kv.second.bsgs); }
+    c->blocks.clear();
+}
+
+extern "C" void hhe_ctx_destroy(hhe_ctx *c)
+{
+    if (!c) return;
+    rt_sync(c->stream);
+    hhe_pasta3_clear_block_cache(c);
+    free_ws(c);
+    rt_free(c->d_rk);
+    for (auto &kv : c->d_gk) rt_free(kv.second);
+    rt_free(c->d_feistel_mask);
+    rt_free(c->d_tables); rt_free(c->d_mods); rt_free(c->d_behz); rt_free(c->d_slot_map);
+    delete c;
+}
+
+extern "C" int hhe_ctx_set_stream(hhe_ctx *c, void *s)
+{
+    if (!c) return HHE_ERR_INVALID;
+    c->stream = (rt_stream)s;
+    return HHE_OK;
+}
+extern "C" int hhe_ctx_sync(hhe_ctx *c)
+{
+    if (!c) return HHE_ERR_INVALID;
+    if (rt_sync(c->stream)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
+    return HHE_OK;
+}
+
+extern "C" int hhe_ctx_reserve(hhe_ctx *c, size_t B)
+{
+    if (!c || B == 0) return HHE_ERR_INVALID;
+    if (B <= c->cap) return HHE_OK;
+    rt_sync(c->stream);
+    free_ws(c);
+    const size_t n = c->n, L = c->L, K = c->K;
+    auto alloc = [&](size_t words) { return (u64 *)rt_malloc(words * 8); };
+    bool ok = true;
+    ok &= !!(c->ws_T = alloc(B * L * K * n));
+    ok &= !!(c->ws_S = alloc(B * 2 * K * n));
+    ok &= !!(c->ws_d = alloc(B * L * n));
+    for (auto &p : c->ws_ct) ok &= !!(p = alloc(B * 2 * L * n));
+    ok &= !!(c->ws_ct3 = alloc(B * 3 * L * n));
+    ok &= !!(c->ws_plain = alloc(B * n));
+    ok &= !!(c->ws_vals = alloc(B * PASTA_T));
+    ok &= !!(c->bz_aq = alloc(B * 2 * L * n));
+    ok &= !!(c->bz_bq = alloc(B * 2 * L * n));
+    ok &= !!(c->bz_ab = alloc(B * 2 * (L + 1) * n));
+    ok &= !!(c->bz_bb = alloc(B * 2 * (L + 1) * n));
+    ok &= !!(c->bz_dq = alloc(B * 3 * L * n));
+    ok &= !!(c->bz_db = alloc(B * 3 * (L + 1) * n));
+    if (!ok) { free_ws(c); hhe_set_error(std::string("hhe_ctx_reserve: ") + rt_last_error()); return HHE_ERR_DEVICE; }
+    c->cap = B;
+    return HHE_OK;
+}
+
+extern "C" uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i)
+{
+    if (!c || !what) return 0;
+    const std::string w(what);
+    if (w == "root" && i >= 0 && i < c->K) return c->roots[i];
+    if (w == "bsk" && i >= 0 && i <= c->L) return c->bsk[i];
+    if (w == "gamma") return c->gamma;
+    if (w == "galois_elt") return galois_elt_from_step(c, i);
+    if (w == "delta" && i >= 0 && i < c->L) return c->apl.delta[i];
+    if (w == "slot_map" && i >= 0 && (size_t)i < c->n) return c->slot_map[i];
+    return 0;
+}
+
+static int upload_key(hhe_ctx *c, u64 *&slot, const uint64_t *ksk)
+{
+    if (!slot) slot = (u64 *)rt_malloc(c->ksk_words() * 8);
+    if (!slot || rt_h2d(slot, ksk, c->ksk_words() * 8, c->stream) || rt_sync(c->stream)) {
+        hhe_set_error(std::string("key upload failed: ") + rt_last_error());
+        return HHE_ERR_DEVICE;
+    }
+    return HHE_OK;
+}
+extern "C" int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk)
+{
+    if (!c || !ksk) return HHE_ERR_INVALID;
+    return upload_key(c, c->d_rk, ksk);
+}
+extern "C" int hhe_set_galois_key(hhe_ctx *c, uint32_t elt, const uint64_t *ksk)
+{
+    if (!c || !ksk || !(elt & 1) || elt >= 2 * c->n) { hhe_set_error("hhe_set_galois_key: invalid Galois element"); return HHE_ERR_INVALID; }
+    u64 *&slot = c->d_gk[elt];
+    return upload_key(c, slot, ksk);
+}
+extern "C" int hhe_has_galois_key(const hhe_ctx *c, uint32_t elt) { return c && c->d_gk.count(elt) ? 1 : 0; }
+
+extern "C" void *hhe_malloc(size_t bytes) { return rt_malloc(bytes); }
+extern "C" void hhe_free(void *p) { rt_free(p); }
+extern "C" int hhe_copy_h2d(hhe_ctx *c, void *d, const void *h, size_t bytes)
+{
+    if (rt_h2d(d, h, bytes, c ? c->stream : nullptr) || rt_sync(c ? c->stream : nullptr)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
+    return HHE_OK;
+}
+extern "C" int hhe_copy_d2h(hhe_ctx *c, void *h, const void *d, size_t bytes)
+{
+    if (rt_d2h(h, d, bytes, c ? c->stream : nullptr) || rt_sync(c ? c->stream : nullptr)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
+    return HHE_OK;
+}

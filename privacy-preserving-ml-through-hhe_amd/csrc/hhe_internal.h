@@ -1,0 +1,77 @@
+// hhe_internal.h -- host-side context of libhhe_gfx950.so (not part of the C ABI).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "hhe_common.h"
+#include "hhe_launch.h"
+
+struct BlockTables {   // public per-(nonce, block index) data of one PASTA block, device resident
+    u64 *diag = nullptr;  // [4][128][L][N] lifted + NTT'd diagonals (multiply_plain operands)
+    u64 *rc = nullptr;    // [4][N] round-constant plaintexts (coefficients mod t)
+    u64 *bsgs = nullptr;  // [4][128][L][N] babystep-giantstep variant of diag (lazy)
+};
+
+struct hhe_ctx {
+    int logn = 0, K = 0, L = 0, device = 0;
+    size_t n = 0;
+    u64 t = 0;
+    std::vector<u64> q;            // K coefficient primes
+    std::vector<u64> bsk;          // L+1: B_0..B_{L-1}, m_sk
+    u64 gamma = 0;
+    std::vector<u64> roots;        // psi per coefficient prime
+    int nmod = 0;                  // K + (L+1) + 1
+    int mod_t = 0;                 // index of the plain modulus
+    rt_stream stream = nullptr;
+
+    // device tables
+    ModDev *d_mods = nullptr;
+    u64 *d_tables = nullptr;
+    BehzDev *d_behz = nullptr;
+    u32 *d_slot_map = nullptr;
+    std::vector<u32> slot_map;
+
+    // argument templates
+    KsFinishArgs ksf{};
+    AddPlainArgs apl{};
+
+    // keys
+    u64 *d_rk = nullptr;
+    std::map<u32, u64 *> d_gk;
+
+    // PASTA public tables
+    std::map<u64, BlockTables> blocks;
+    u64 *d_feistel_mask = nullptr;  // [L][N] NTT form of the sbox_feistel mask plaintext
+
+    // workspace
+    size_t cap = 0;
+    u64 *ws_T = nullptr;     // [B][L][K][N]
+    u64 *ws_S = nullptr;     // [B][2][K][N]
+    u64 *ws_d = nullptr;     // [B][L][N]
+    u64 *ws_ct[4] = {nullptr, nullptr, nullptr, nullptr};  // [B][2][L][N] each
+    u64 *ws_ct3 = nullptr;   // [B][3][L][N]
+    u64 *ws_plain = nullptr; // [B][N]
+    u64 *ws_vals = nullptr;  // [B][128]
+    u64 *bz_aq = nullptr, *bz_bq = nullptr;  // [B][2][L][N]
+    u64 *bz_ab = nullptr, *bz_bb = nullptr;  // [B][2][L+1][N]
+    u64 *bz_dq = nullptr;    // [B][3][L][N]
+    u64 *bz_db = nullptr;    // [B][3][L+1][N]
+
+    size_t ct_words() const { return (size_t)2 * L * n; }
+    size_t ksk_words() const { return (size_t)L * 2 * K * n; }
+};
+
+// number theory (hhe_context.cpp)
+bool nt_is_prime(u64 v);
+bool nt_get_primes(u64 factor, int bits, size_t count, std::vector<u64> &out);
+u64 nt_minimal_primitive_root(u64 degree, u64 q);
+u64 nt_invmod(u64 a, u64 m);
+u64 nt_mulmod(u64 a, u64 b, u64 m);
+u64 nt_powmod(u64 a, u64 e, u64 m);
+std::vector<int> nt_naf(int value);
+u32 galois_elt_from_step(const hhe_ctx *c, int step);
+
+// PASTA-3 public randomness (hhe_pasta_public.cpp)
+void pasta3_block_randomness(u64 t, u64 nonce, u64 block, u64 *mats, u64 *rcs);
+
+void hhe_set_error(const std::string &msg);

@@ -1,0 +1,425 @@
+// hhe_kernel_bodies.h -- the bodies of every gfx950 kernel on the transciphering path,
+// written once as host/device inline functions of (block, thread) so that the
+// tests-only emulator (tests/emu) can drive exactly the same index arithmetic on the
+// CPU.  hhe_kernels.hip wraps each body in a __global__ kernel; nothing here is a
+// CPU fallback for the product.
+//
+// NTT: negacyclic Cooley-Tukey forward / Gentleman-Sande inverse with the transform
+// order of SEAL (seal/util/dwthandler.h:94-356; root_powers[bitrev(k)] = psi^k), Harvey
+// lazy butterflies in [0,4q) / [0,2q) (seal/util/ntt.h:30-61), split in two passes
+// (N = N1 x N2).  One workgroup stages a tile of 2^logm points x 2^logc independent
+// lanes in LDS and runs radix-16/8/4 register rounds over it.
+#pragma once
+#include "hhe_modarith.h"
+
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_TILE_LOG = 12;                    // 4096 points per tile
+constexpr int NTT_LDS_ELEMS = (1 << NTT_TILE_LOG) + 512;  // rows of pitch C+1
+
+template <int LOGM> struct NttSched;  // register-radix schedule per sub-transform size
+template <> struct NttSched<5> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
+template <> struct NttSched<6> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
+template <> struct NttSched<7> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 4 : 3; } };
+template <> struct NttSched<8> { static constexpr int R = 2; static constexpr int rho(int i) { return 4; } };
+
+struct NttGeom {
+    int n, M, C, pitch, N_over_M;
+    int poly, mod_index, tile;
+};
+HD NttGeom ntt_geom(const NttArgs &a, int bx, int by)
+{
+    NttGeom g;
+    g.n = 1 << a.logn;
+    g.M = 1 << a.logm;
+    g.C = 1 << a.logc;
+    g.pitch = g.C + 1;
+    g.N_over_M = g.n >> a.logm;
+    g.poly = by;
+    g.mod_index = a.mod_base + by % a.mod_cycle;
+    g.tile = bx;
+    return g;
+}
+// global coefficient index of (x, lane)
+template <bool STRIDED> HD int ntt_gidx(const NttGeom &g, int x, int lane)
+{
+    if (STRIDED) return x * g.N_over_M + g.tile * g.C + lane;
+    return (g.tile * g.C + lane) * g.M + x;
+}
+
+template <bool STRIDED, bool INVERSE>
+HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
+{
+    constexpr bool FIRST = (STRIDED != INVERSE);
+    const NttGeom g = ntt_geom(a, bx, by);
+    const ModDev &m = a.mods[g.mod_index];
+    const u64 *src;
+    if (FIRST) {
+        const int ip = a.src_item_polys > 0 ? a.src_item_polys : a.count;
+        src = a.src + (size_t)(g.poly / ip) * a.src_item_stride + (size_t)((g.poly % ip) / a.src_div) * g.n;
+    } else src = a.dst + (size_t)g.poly * g.n;
+    const int E = g.M * g.C;
+    for (int e = tid; e < E; e += NTT_THREADS) {
+        int x, lane;
+        if (STRIDED) { lane = e & (g.C - 1); x = e >> a.logc; }
+        else { x = e & (g.M - 1); lane = e >> a.logm; }
+        u64 v = src[ntt_gidx<STRIDED>(g, x, lane)];
+        if (FIRST) {
+            if (a.load_op == LOAD_DIGIT) v = reduce64(v, m);
+            else if (a.load_op == LOAD_LIFT) v = (v >= ((a.t + 1) >> 1)) ? v + (m.q - a.t) : v;
+        }
+        lds[x * g.pitch + lane] = v;
+    }
+}
+
+// one register round: RHO stages starting at local stage S0 of a 2^LOGM transform
+template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE>
+HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
+{
+    const NttGeom g = ntt_geom(a, bx, by);
+    const ModDev &m = a.mods[g.mod_index];
+    const u64 q = m.q, q2 = q << 1;
+    const u64 *W = INVERSE ? m.iw : m.w;
+    const u64 *WS = INVERSE ? m.iws : m.ws;
+    constexpr int LO_BITS = LOGM - S0 - RHO;
+    constexpr int RAD = 1 << RHO;
+    const int groups = (g.M >> RHO) * g.C;
+    for (int grp = tid; grp < groups; grp += NTT_THREADS) {
+        const int lane = grp & (g.C - 1);
+        const int sub = grp >> a.logc;
+        const int hi = sub >> LO_BITS;
+        const int lo = sub & ((1 << LO_BITS) - 1);
+        const int x0 = (hi << (LOGM - S0)) + lo;
+        const int P = STRIDED ? 1 : g.N_over_M + g.tile * g.C + lane;
+        const int tb = (P << S0) + hi;
+        u64 v[RAD];
+#pragma unroll
+        for (int k = 0; k < RAD; k++) v[k] = lds[(x0 + (k << LO_BITS)) * g.pitch + lane];
+        if (!INVERSE) {
+#pragma unroll
+            for (int u = 0; u < RHO; u++) {
+                const int half = 1 << (RHO - 1 - u);
+#pragma unroll
+                for (int b = 0; b < (1 << u); b++) {
+                    const u64 w = W[(tb << u) + b], ws = WS[(tb << u) + b];
+#pragma unroll
+                    for (int j = 0; j < half; j++) {
+                        const int k0 = b * 2 * half + j, k1 = k0 + half;
+                        u64 x = v[k0];
+                        x -= (x >= q2) ? q2 : 0;
+                        const u64 y = shoup_lazy(v[k1], w, ws, q);
+                        v[k0] = x + y;
+                        v[k1] = x + q2 - y;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = RHO - 1; u >= 0; u--) {
+                const int half = 1 << (RHO - 1 - u);
+#pragma unroll
+                for (int b = 0; b < (1 << u); b++) {
+                    const u64 w = W[(tb << u) + b], ws = WS[(tb << u) + b];
+#pragma unroll
+                    for (int j = 0; j < half; j++) {
+                        const int k0 = b * 2 * half + j, k1 = k0 + half;
+                        const u64 x = v[k0], y = v[k1];
+                        u64 s = x + y;
+                        s -= (s >= q2) ? q2 : 0;
+                        v[k0] = s;
+                        v[k1] = shoup_lazy(x + q2 - y, w, ws, q);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RAD; k++) lds[(x0 + (k << LO_BITS)) * g.pitch + lane] = v[k];
+    }
+}
+
+template <bool STRIDED, bool INVERSE>
+HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds)
+{
+    constexpr bool LAST = (STRIDED == INVERSE);
+    const NttGeom g = ntt_geom(a, bx, by);
+    const ModDev &m = a.mods[g.mod_index];
+    const u64 q = m.q, q2 = q << 1;
+    u64 *dst = a.dst + (size_t)g.poly * g.n;
+    const int E = g.M * g.C;
+    for (int e = tid; e < E; e += NTT_THREADS) {
+        int x, lane;
+        if (STRIDED) { lane = e & (g.C - 1); x = e >> a.logc; }
+        else { x = e & (g.M - 1); lane = e >> a.logm; }
+        const int gi = ntt_gidx<STRIDED>(g, x, lane);
+        u64 v = lds[x * g.pitch + lane];
+        if (LAST) {
+            if (INVERSE) {
+                if (a.store_op == STORE_SCALE_T) v = shoup_lazy(v, m.ninv_t, m.ninv_t_s, q);
+                else v = shoup_lazy(v, m.ninv, m.ninv_s, q);
+                v -= (v >= q) ? q : 0;
+            } else {
+                v -= (v >= q2) ? q2 : 0;
+                v -= (v >= q) ? q : 0;
+                if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
+                    const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
+                    v = mulmod(v, mp[a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi], m);
+                    if (a.store_op == STORE_MAC) {
+                        u64 *ap = a.acc + (size_t)g.poly * g.n + gi;
+                        *ap = addmod(*ap, v, q);
+                        continue;
+                    }
+                }
+            }
+        }
+        dst[gi] = v;
+    }
+}
+
+// ------------------------------------------------------------------ element-wise
+
+HD void elt_body(const EltArgs &a, int op, size_t gid)
+{
+    const int n = 1 << a.logn;
+    const size_t p = gid >> a.logn;
+    if (p >= (size_t)a.count) return;
+    const size_t i = gid & (n - 1);
+    const ModDev &m = a.mods[a.mod_base + (int)(p % a.mod_cycle)];
+    const size_t bp = a.b_cycle ? p % a.b_cycle : p;
+    const u64 x = op == ELT_BCAST ? 0 : a.a[gid];
+    u64 r;
+    switch (op) {
+    case ELT_BCAST: r = a.b[bp * n + i]; break;
+    case ELT_ADD: r = addmod(x, a.b[bp * n + i], m.q); break;
+    case ELT_SUB: r = submod(x, a.b[bp * n + i], m.q); break;
+    case ELT_NEG: r = negmod(x, m.q); break;
+    case ELT_MUL: r = mulmod(x, a.b[bp * n + i], m); break;
+    case ELT_MAC: r = addmod(a.out[gid], mulmod(x, a.b[bp * n + i], m), m.q); break;
+    default: r = x; break;
+    }
+    a.out[gid] = r;
+}
+
+// GaloisTool::apply_galois as a gather (seal/util/galois.h:32)
+HD void galois_body(const GaloisArgs &a, size_t gid)
+{
+    const u32 n = 1u << a.logn;
+    const size_t p = gid >> a.logn;
+    if (p >= (size_t)a.count) return;
+    const u32 k = (u32)(gid & (n - 1));
+    const size_t item = p / a.L, limb = p % a.L;
+    const u64 q = a.mods[limb].q;
+    const u32 j = (u32)(((u64)k * a.einv) & (2 * n - 1));
+    const u64 *src = a.in + item * a.in_item_stride + limb * n;
+    u64 v = (j < n) ? src[j] : negmod(src[j - n], q);
+    a.out[item * a.out_item_stride + limb * n + k] = v;
+}
+
+// key-switch inner product: gid over [B][K][N]
+HD void ks_mac_body(const KsMacArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = gid & (n - 1);
+    const size_t bj = gid >> a.logn;
+    const int J = (int)(bj % a.K);
+    const size_t b = bj / a.K;
+    if (b >= (size_t)a.B) return;
+    const ModDev &m = a.mods[J];
+    Acc128 s0 = {0, 0}, s1 = {0, 0};
+    u64 r0 = 0, r1 = 0;
+    for (int I = 0; I < a.L; I++) {
+        const u64 t = a.T[((b * a.L + I) * a.K + J) * n + i];
+        acc_mac(s0, t, a.key[(((size_t)I * 2 + 0) * a.K + J) * n + i]);
+        acc_mac(s1, t, a.key[(((size_t)I * 2 + 1) * a.K + J) * n + i]);
+        if ((I & 3) == 3) {  // q < 2^61: four products stay below 2^124
+            r0 = barrett128(s0.lo, s0.hi, m); s0.lo = r0; s0.hi = 0;
+            r1 = barrett128(s1.lo, s1.hi, m); s1.lo = r1; s1.hi = 0;
+        }
+    }
+    a.S[((b * 2 + 0) * a.K + J) * n + i] = barrett128(s0.lo, s0.hi, m);
+    a.S[((b * 2 + 1) * a.K + J) * n + i] = barrett128(s1.lo, s1.hi, m);
+}
+
+// key-switch mod-down by the special prime with rounding: gid over [B][2][L][N]
+HD void ks_finish_body(const KsFinishArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = gid & (n - 1);
+    size_t r = gid >> a.logn;
+    const int j = (int)(r % a.L); r /= a.L;
+    const int k = (int)(r & 1);
+    const size_t b = r >> 1;
+    if (b >= (size_t)a.B) return;
+    const ModDev &m = a.mods[j];
+    const u64 qsp = a.mods[a.K - 1].q;
+    const u64 sp = a.S[((b * 2 + k) * a.K + (a.K - 1)) * n + i];
+    const u64 rk = addmod(sp, a.half, qsp);
+    const u64 rj = reduce64(rk, m);
+    u64 v = a.S[((b * 2 + k) * a.K + j) * n + i];
+    v = addmod(submod(v, rj, m.q), a.half_mod[j], m.q);
+    v = shoup_mul(v, a.qsp_inv[j], a.qsp_inv_s[j], m.q);
+    if ((a.base_mask >> k) & 1) v = addmod(v, a.base[b * a.base_item_stride + ((size_t)k * a.L + j) * n + i], m.q);
+    a.out[gid] = v;
+}
+
+// add_plain / sub_plain with the BFV scaling variant (seal/util/scalingvariant.h:23)
+// gid over [B][N]; also carries c1 through (optionally negated).
+HD void add_plain_body(const AddPlainArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = gid & (n - 1);
+    const size_t b = gid >> a.logn;
+    if (b >= (size_t)a.B) return;
+    const u64 mval = a.plain_ptrs ? a.plain_ptrs[b][a.plain_shift + i] : a.plain[(a.plain_bcast ? 0 : b * n) + i];
+    // fix = floor((m * (Q mod t) + (t+1)/2) / t)
+    u64 lo = mval * a.q_mod_t, hi = mulhi64(mval, a.q_mod_t);
+    lo += a.thr; hi += (lo < a.thr);
+    u64 fix = barrett_quo(lo, hi, a.t_r_lo, a.t_r_hi);
+    u64 rem = lo - fix * a.t;
+    while (rem >= a.t) { rem -= a.t; fix++; }
+    for (int j = 0; j < a.L; j++) {
+        const ModDev &m = a.mods[j];
+        Acc128 s = {0, 0};
+        acc_mac(s, mval, a.delta[j]);
+        acc_add(s, fix);
+        const u64 sc = barrett128(s.lo, s.hi, m);
+        const size_t o0 = ((b * 2 + 0) * a.L + j) * n + i, o1 = ((b * 2 + 1) * a.L + j) * n + i;
+        u64 c0 = a.ct[o0], c1 = a.ct[o1];
+        if (a.negate_ct) { c0 = negmod(c0, m.q); c1 = negmod(c1, m.q); }
+        a.out[o0] = a.subtract ? submod(c0, sc, m.q) : addmod(c0, sc, m.q);
+        a.out[o1] = c1;
+    }
+}
+
+// BatchEncoder::encode slot scatter: gid over [B][count * (second_off>=0 ? 2 : 1)]
+HD void encode_scatter_body(const EncodeArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const int per = a.count * (a.second_off >= 0 ? 2 : 1);
+    const size_t b = gid / per;
+    if (b >= (size_t)a.B) return;
+    const int v = (int)(gid % per);
+    const int slot = v < a.count ? v : a.second_off + (v - a.count);
+    u64 x = a.vals[b * a.stride + v];
+    x = x >= a.t ? x % a.t : x;
+    a.out[b * n + a.slot_map[slot]] = x;
+}
+
+// diagonals of the two PASTA matrices placed in slot order (pasta_3_seal.cpp:390-401):
+// diag_i[j] = M1[j][(j - i) mod 128], diag_i[j + N/2] = M2[j][(j - i) mod 128].
+// gid over [4 layers][128 diag][2 halves][128 j]
+HD void diag_body(const DiagArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const int j = (int)(gid & 127);
+    const int h = (int)((gid >> 7) & 1);
+    const int i = (int)((gid >> 8) & 127);
+    const int layer = (int)(gid >> 15);
+    if (layer >= PASTA_R + 1) return;
+    const u64 v = a.mats[(((size_t)layer * 2 + h) * PASTA_T + j) * PASTA_T + ((j + PASTA_T - i) & 127)];
+    const size_t slot = (size_t)j + (h ? n / 2 : 0);
+    a.out[((size_t)layer * PASTA_T + i) * n + a.slot_map[slot]] = v;
+}
+
+// ------------------------------------------------------------------ BEHZ
+// fastbconv_m_tilde + sm_mrq (seal/util/rns.h:213-219): gid over [P][N]
+HD void behz_extend_body(const BehzExtendArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = gid & (n - 1);
+    const size_t p = gid >> a.logn;
+    if (p >= (size_t)a.P) return;
+    const BehzDev &z = *a.bz;
+    const int L = a.L;
+    const u64 MTm = 0xffffffffULL, MT = 1ULL << 32;
+    u64 tmp[HHE_MAXL];
+    u64 ymt = 0;
+    for (int l = 0; l < L; l++) {
+        const ModDev &m = a.mods[l];
+        u64 v = mulmod(a.x[(p * L + l) * n + i], z.mt_mod_q[l], m);
+        v = shoup_mul(v, z.inv_punct_q[l], z.inv_punct_q_s[l], m.q);
+        tmp[l] = v;
+        ymt += v * z.punct_q_mt[l];
+    }
+    ymt &= MTm;
+    const u64 r = (ymt * z.neg_inv_q_mt) & MTm;
+    for (int pb = 0; pb <= L; pb++) {
+        const ModDev &mp = a.mods[a.K + pb];
+        Acc128 s = {0, 0};
+        for (int l = 0; l < L; l++) {
+            acc_mac(s, tmp[l], z.punct_q_bsk[l][pb]);
+            if ((l & 3) == 3) { s.lo = barrett128(s.lo, s.hi, mp); s.hi = 0; }
+        }
+        const u64 rr = r >= (MT >> 1) ? r + (mp.q - MT) : r;
+        acc_mac(s, z.q_mod_bsk[pb], rr);
+        const u64 v = barrett128(s.lo, s.hi, mp);
+        a.xb[(p * (L + 1) + pb) * n + i] = mulmod(v, z.inv_mt_bsk[pb], mp);
+    }
+}
+
+// ciphertext tensor product in the NTT domain: gid over [B][limbs][N]
+HD void tensor_body(const TensorArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = gid & (n - 1);
+    size_t r = gid >> a.logn;
+    const int j = (int)(r % a.limbs);
+    const size_t b = r / a.limbs;
+    if (b >= (size_t)a.B) return;
+    const ModDev &m = a.mods[a.mod_base + j];
+    const size_t lim = a.limbs;
+    const u64 a0 = a.a[((b * 2 + 0) * lim + j) * n + i], a1 = a.a[((b * 2 + 1) * lim + j) * n + i];
+    const u64 b0 = a.b[((b * 2 + 0) * lim + j) * n + i], b1 = a.b[((b * 2 + 1) * lim + j) * n + i];
+    a.d[((b * 3 + 0) * lim + j) * n + i] = mulmod(a0, b0, m);
+    Acc128 s = {0, 0};
+    acc_mac(s, a0, b1);
+    acc_mac(s, a1, b0);
+    a.d[((b * 3 + 1) * lim + j) * n + i] = barrett128(s.lo, s.hi, m);
+    a.d[((b * 3 + 2) * lim + j) * n + i] = mulmod(a1, b1, m);
+}
+
+// fast_floor + fastbconv_sk (seal/util/rns.h:221-228): gid over [P][N]
+HD void behz_floor_body(const BehzFloorArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = gid & (n - 1);
+    const size_t p = gid >> a.logn;
+    if (p >= (size_t)a.P) return;
+    const BehzDev &z = *a.bz;
+    const int L = a.L;
+    u64 tq[HHE_MAXL], f[HHE_MAXL + 1], tb[HHE_MAXL];
+    for (int l = 0; l < L; l++)
+        tq[l] = shoup_mul(a.dq[(p * L + l) * n + i], z.inv_punct_q[l], z.inv_punct_q_s[l], a.mods[l].q);
+    for (int pb = 0; pb <= L; pb++) {
+        const ModDev &mp = a.mods[a.K + pb];
+        Acc128 s = {0, 0};
+        for (int l = 0; l < L; l++) {
+            acc_mac(s, tq[l], z.punct_q_bsk[l][pb]);
+            if ((l & 3) == 3) { s.lo = barrett128(s.lo, s.hi, mp); s.hi = 0; }
+        }
+        const u64 conv = barrett128(s.lo, s.hi, mp);
+        const u64 x = a.db[(p * (L + 1) + pb) * n + i];
+        f[pb] = mulmod(addmod(x, mp.q - conv, mp.q), z.inv_q_bsk[pb], mp);
+    }
+    for (int l = 0; l < L; l++) tb[l] = mulmod(f[l], z.inv_punct_B[l], a.mods[a.K + l]);
+    const ModDev &ms = a.mods[a.K + L];
+    Acc128 s = {0, 0};
+    for (int l = 0; l < L; l++) {
+        acc_mac(s, tb[l], z.punct_B_msk[l]);
+        if ((l & 3) == 3) { s.lo = barrett128(s.lo, s.hi, ms); s.hi = 0; }
+    }
+    const u64 conv = barrett128(s.lo, s.hi, ms);
+    const u64 alpha = mulmod(addmod(conv, ms.q - f[L], ms.q), z.inv_B_msk, ms);
+    const bool negative = alpha > (z.msk >> 1);
+    for (int j = 0; j < L; j++) {
+        const ModDev &m = a.mods[j];
+        Acc128 t = {0, 0};
+        for (int l = 0; l < L; l++) {
+            acc_mac(t, tb[l], z.punct_B_q[l][j]);
+            if ((l & 3) == 3) { t.lo = barrett128(t.lo, t.hi, m); t.hi = 0; }
+        }
+        u64 v = barrett128(t.lo, t.hi, m);
+        Acc128 c = {v, 0};
+        if (negative) acc_mac(c, z.msk - alpha, z.B_mod_q[j]);
+        else acc_mac(c, alpha, z.neg_B_mod_q[j]);
+        a.out[(p * L + j) * n + i] = barrett128(c.lo, c.hi, m);
+    }
+}

@@ -1,0 +1,138 @@
+// hhe_kernels.hip -- gfx950 (MI355X, wave64) kernels for the PASTA-3 -> BFV transciphering
+// path: RNS negacyclic NTT/INTT, coefficient-wise modular arithmetic, Galois permutation,
+// key-switch gadget product / mod-down, BEHZ base conversions.  Integer lanes only
+// (v_mul_hi_u32 / v_mad_u64_u32), no MFMA: this is exact modular arithmetic.
+// Bodies live in hhe_kernel_bodies.h; this file is the __global__ wrappers + launchers.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "hhe_kernel_bodies.h"
+#include "hhe_launch.h"
+
+static thread_local char g_rt_err[256] = "";
+static int rt_check(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return 0;
+    snprintf(g_rt_err, sizeof(g_rt_err), "%s: %s", what, hipGetErrorString(e));
+    return -1;
+}
+const char *rt_backend_name() { return "hip-gfx950"; }
+const char *rt_last_error() { return g_rt_err; }
+int rt_set_device(int d) { return rt_check(hipSetDevice(d), "hipSetDevice"); }
+void *rt_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (rt_check(hipMalloc(&p, bytes ? bytes : 8), "hipMalloc")) return nullptr;
+    return p;
+}
+void rt_free(void *p) { if (p) (void)hipFree(p); }
+int rt_h2d(void *d, const void *s, size_t n, rt_stream st) { return rt_check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st), "h2d"); }
+int rt_d2h(void *d, const void *s, size_t n, rt_stream st) { return rt_check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st), "d2h"); }
+int rt_d2d(void *d, const void *s, size_t n, rt_stream st) { return rt_check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st), "d2d"); }
+int rt_memset(void *d, int v, size_t n, rt_stream st) { return rt_check(hipMemsetAsync(d, v, n, (hipStream_t)st), "memset"); }
+int rt_sync(rt_stream st) { return rt_check(hipStreamSynchronize((hipStream_t)st), "sync"); }
+
+// ---------------------------------------------------------------- NTT
+template <int LOGM, bool STRIDED, bool INVERSE, int R>
+struct NttRounds {
+    // forward: rounds 0..R-1 ascending; inverse: descending
+    template <int I, int S0>
+    static __device__ __forceinline__ void fwd(const NttArgs &a, u64 *lds)
+    {
+        if constexpr (I < R) {
+            constexpr int RHO = NttSched<LOGM>::rho(I);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+            __syncthreads();
+            fwd<I + 1, S0 + RHO>(a, lds);
+        }
+    }
+    template <int I, int SEND>
+    static __device__ __forceinline__ void inv(const NttArgs &a, u64 *lds)
+    {
+        if constexpr (I >= 0) {
+            constexpr int RHO = NttSched<LOGM>::rho(I);
+            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+            __syncthreads();
+            inv<I - 1, SEND - RHO>(a, lds);
+        }
+    }
+};
+
+template <int LOGM, bool STRIDED, bool INVERSE>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttArgs a)
+{
+    __shared__ u64 lds[NTT_LDS_ELEMS];
+    ntt_body_load<STRIDED, INVERSE>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    __syncthreads();
+    constexpr int R = NttSched<LOGM>::R;
+    if constexpr (!INVERSE) NttRounds<LOGM, STRIDED, INVERSE, R>::template fwd<0, 0>(a, lds);
+    else NttRounds<LOGM, STRIDED, INVERSE, R>::template inv<R - 1, LOGM>(a, lds);
+    ntt_body_store<STRIDED, INVERSE>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+}
+
+template <bool STRIDED, bool INVERSE>
+static void launch_pass(NttArgs a, int logm, int other, hipStream_t st)
+{
+    a.logm = logm;
+    int logc = NTT_TILE_LOG - logm;
+    if (logc > other) logc = other;
+    a.logc = logc;
+    dim3 grid(1u << (other - logc), (unsigned)a.count);
+    switch (logm) {
+    case 5: hipLaunchKernelGGL((ntt_pass_kernel<5, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((ntt_pass_kernel<6, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), 0, st, a); break;
+    case 7: hipLaunchKernelGGL((ntt_pass_kernel<7, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((ntt_pass_kernel<8, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), 0, st, a); break;
+    default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", logm); break;
+    }
+}
+void k_ntt(const NttArgs &a, bool inverse, rt_stream s)
+{
+    if (a.count <= 0) return;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    hipStream_t st = (hipStream_t)s;
+    if (!inverse) {
+        launch_pass<true, false>(a, n1, n2, st);   // strided pass: global stages 0..n1-1
+        launch_pass<false, false>(a, n2, n1, st);  // row pass: stages n1..n-1
+    } else {
+        launch_pass<false, true>(a, n2, n1, st);
+        launch_pass<true, true>(a, n1, n2, st);
+    }
+}
+
+// ---------------------------------------------------------------- element-wise family
+constexpr int ELT_THREADS = 256;
+static inline unsigned nblocks(size_t total) { return (unsigned)((total + ELT_THREADS - 1) / ELT_THREADS); }
+#define GID ((size_t)blockIdx.x * ELT_THREADS + threadIdx.x)
+
+__global__ void __launch_bounds__(ELT_THREADS) elt_kernel(EltArgs a, int op) { elt_body(a, op, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) galois_kernel(GaloisArgs a) { galois_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) ks_mac_kernel(KsMacArgs a) { ks_mac_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) ks_finish_kernel(KsFinishArgs a) { ks_finish_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) add_plain_kernel(AddPlainArgs a) { add_plain_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) encode_scatter_kernel(EncodeArgs a) { encode_scatter_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) diag_kernel(DiagArgs a) { diag_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) behz_extend_kernel(BehzExtendArgs a) { behz_extend_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) tensor_kernel(TensorArgs a) { tensor_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) behz_floor_kernel(BehzFloorArgs a) { behz_floor_body(a, GID); }
+
+#define LAUNCH1D(kern, total, s, ...)                                                                   \
+    do {                                                                                                \
+        size_t _t = (total);                                                                            \
+        if (_t) hipLaunchKernelGGL(kern, dim3(nblocks(_t)), dim3(ELT_THREADS), 0, (hipStream_t)(s), __VA_ARGS__); \
+    } while (0)
+
+void k_elt(const EltArgs &a, int op, rt_stream s) { LAUNCH1D(elt_kernel, (size_t)a.count << a.logn, s, a, op); }
+void k_galois(const GaloisArgs &a, rt_stream s) { LAUNCH1D(galois_kernel, (size_t)a.count << a.logn, s, a); }
+void k_ks_mac(const KsMacArgs &a, rt_stream s) { LAUNCH1D(ks_mac_kernel, ((size_t)a.B * a.K) << a.logn, s, a); }
+void k_ks_finish(const KsFinishArgs &a, rt_stream s) { LAUNCH1D(ks_finish_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
+void k_add_plain(const AddPlainArgs &a, rt_stream s) { LAUNCH1D(add_plain_kernel, (size_t)a.B << a.logn, s, a); }
+void k_encode_scatter(const EncodeArgs &a, rt_stream s)
+{
+    LAUNCH1D(encode_scatter_kernel, (size_t)a.B * a.count * (a.second_off >= 0 ? 2 : 1), s, a);
+}
+void k_diag(const DiagArgs &a, rt_stream s) { LAUNCH1D(diag_kernel, (size_t)(PASTA_R + 1) * PASTA_T * 2 * PASTA_T, s, a); }
+void k_behz_extend(const BehzExtendArgs &a, rt_stream s) { LAUNCH1D(behz_extend_kernel, (size_t)a.P << a.logn, s, a); }
+void k_tensor(const TensorArgs &a, rt_stream s) { LAUNCH1D(tensor_kernel, ((size_t)a.B * a.limbs) << a.logn, s, a); }
+void k_behz_floor(const BehzFloorArgs &a, rt_stream s) { LAUNCH1D(behz_floor_kernel, (size_t)a.P << a.logn, s, a); }

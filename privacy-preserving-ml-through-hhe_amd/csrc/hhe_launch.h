@@ -1,0 +1,35 @@
+// hhe_launch.h -- launch + device-runtime interface between the host driver and the kernels.
+// Implemented by hhe_kernels.hip (gfx950, the product) and, for CPU-side unit tests of
+// the index arithmetic only, by tests/emu/hhe_launch_emu.cpp.
+#pragma once
+#include "hhe_common.h"
+
+typedef void *rt_stream;
+
+// device runtime
+const char *rt_backend_name();
+int rt_set_device(int device);
+void *rt_malloc(size_t bytes);
+void rt_free(void *p);
+int rt_h2d(void *dst, const void *src, size_t bytes, rt_stream s);
+int rt_d2h(void *dst, const void *src, size_t bytes, rt_stream s);
+int rt_d2d(void *dst, const void *src, size_t bytes, rt_stream s);
+int rt_memset(void *dst, int v, size_t bytes, rt_stream s);
+int rt_sync(rt_stream s);
+const char *rt_last_error();
+
+// kernels (all asynchronous on `s`)
+void k_ntt(const NttArgs &a, bool inverse, rt_stream s);  // runs both passes; a.logm/logc ignored
+void k_elt(const EltArgs &a, int op, rt_stream s);
+void k_galois(const GaloisArgs &a, rt_stream s);
+void k_ks_mac(const KsMacArgs &a, rt_stream s);
+void k_ks_finish(const KsFinishArgs &a, rt_stream s);
+void k_add_plain(const AddPlainArgs &a, rt_stream s);
+void k_encode_scatter(const EncodeArgs &a, rt_stream s);
+void k_diag(const DiagArgs &a, rt_stream s);
+void k_behz_extend(const BehzExtendArgs &a, rt_stream s);
+void k_tensor(const TensorArgs &a, rt_stream s);
+void k_behz_floor(const BehzFloorArgs &a, rt_stream s);
+
+// split of logn into the two pass sizes (strided pass n1, row pass n2)
+inline void ntt_split(int logn, int &n1, int &n2) { n1 = logn / 2; n2 = logn - n1; }

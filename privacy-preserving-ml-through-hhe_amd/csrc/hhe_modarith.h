@@ -1,0 +1,72 @@
+// hhe_modarith.h -- 64-bit modular arithmetic in integer lanes (moduli up to 61 bits).
+// Device code uses __umul64hi (v_mul_hi_u32 / v_mad_u64_u32 chains on gfx950); the host
+// path (table generation, tests-only emulator) uses unsigned __int128.
+#pragma once
+#include "hhe_common.h"
+
+HD u64 mulhi64(u64 a, u64 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// x*w mod q in [0,2q) for any x < 2^64, with ws = floor(w * 2^64 / q), w < q.
+HD u64 shoup_lazy(u64 x, u64 w, u64 ws, u64 q) { return x * w - mulhi64(x, ws) * q; }
+HD u64 shoup_mul(u64 x, u64 w, u64 ws, u64 q)
+{
+    u64 r = shoup_lazy(x, w, ws, q);
+    return r >= q ? r - q : r;
+}
+
+HD u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
+HD u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+HD u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// Quotient estimate floor((x1:x0) * R / 2^128), R = (r_hi:r_lo) = floor(2^128/q).
+// Never above the true quotient and at most 3 below it.
+HD u64 barrett_quo(u64 x0, u64 x1, u64 r_lo, u64 r_hi)
+{
+    u64 carry = mulhi64(x0, r_lo);
+    u64 t2lo = x0 * r_hi, t2hi = mulhi64(x0, r_hi);
+    u64 s1 = t2lo + carry;
+    u64 t3 = t2hi + (s1 < t2lo);
+    u64 ulo = x1 * r_lo, uhi = mulhi64(x1, r_lo);
+    u64 s2 = s1 + ulo;
+    u64 c2 = uhi + (s2 < ulo);
+    return x1 * r_hi + t3 + c2;
+}
+// (x1:x0) mod q, q < 2^61
+HD u64 barrett128(u64 x0, u64 x1, const ModDev &m)
+{
+    u64 quo = barrett_quo(x0, x1, m.r_lo, m.r_hi);
+    u64 r = x0 - quo * m.q;
+    u64 q2 = m.q << 1;
+    r -= (r >= q2) ? q2 : 0;
+    r -= (r >= m.q) ? m.q : 0;
+    return r;
+}
+HD u64 mulmod(u64 a, u64 b, const ModDev &m) { return barrett128(a * b, mulhi64(a, b), m); }
+// x mod q for a single word
+HD u64 reduce64(u64 x, const ModDev &m)
+{
+    u64 r = x - mulhi64(x, m.r_hi) * m.q;
+    return r >= m.q ? r - m.q : r;
+}
+// 128-bit lazy accumulator
+struct Acc128 {
+    u64 lo, hi;
+};
+HD void acc_mac(Acc128 &a, u64 x, u64 y)
+{
+    u64 plo = x * y, phi = mulhi64(x, y);
+    a.lo += plo;
+    a.hi += phi + (a.lo < plo);
+}
+HD void acc_add(Acc128 &a, u64 x)
+{
+    a.lo += x;
+    a.hi += (a.lo < x);
+}

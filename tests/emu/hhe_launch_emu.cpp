@@ -1,0 +1,96 @@
+// hhe_launch_emu.cpp -- TESTS ONLY.  Implements csrc/hhe_launch.h on the CPU by looping the
+// kernel bodies of csrc/hhe_kernel_bodies.h over (block, thread) with a barrier between
+// phases, so the `-m "not gpu"` suite can check the kernels' index arithmetic and the host
+// schedule against the oracle without a GPU.  It is never built into or loaded by the
+// product library (libhhe_gfx950.so), which has no CPU path.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "hhe_kernel_bodies.h"
+#include "hhe_launch.h"
+
+const char *rt_backend_name() { return "cpu-emulator(tests-only)"; }
+const char *rt_last_error() { return "emu"; }
+int rt_set_device(int) { return 0; }
+void *rt_malloc(size_t b) { return malloc(b ? b : 8); }
+void rt_free(void *p) { free(p); }
+int rt_h2d(void *d, const void *s, size_t n, rt_stream) { memcpy(d, s, n); return 0; }
+int rt_d2h(void *d, const void *s, size_t n, rt_stream) { memcpy(d, s, n); return 0; }
+int rt_d2d(void *d, const void *s, size_t n, rt_stream) { memmove(d, s, n); return 0; }
+int rt_memset(void *d, int v, size_t n, rt_stream) { memset(d, v, n); return 0; }
+int rt_sync(rt_stream) { return 0; }
+
+template <int LOGM, bool STRIDED, bool INVERSE, int I, int S0>
+static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
+{
+    if constexpr (I < NttSched<LOGM>::R) {
+        constexpr int RHO = NttSched<LOGM>::rho(I);
+        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false>(a, bx, by, t, lds);
+        rounds_fwd<LOGM, STRIDED, INVERSE, I + 1, S0 + RHO>(a, bx, by, lds);
+    }
+}
+template <int LOGM, bool STRIDED, bool INVERSE, int I, int SEND>
+static void rounds_inv(const NttArgs &a, int bx, int by, u64 *lds)
+{
+    if constexpr (I >= 0) {
+        constexpr int RHO = NttSched<LOGM>::rho(I);
+        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true>(a, bx, by, t, lds);
+        rounds_inv<LOGM, STRIDED, INVERSE, I - 1, SEND - RHO>(a, bx, by, lds);
+    }
+}
+template <int LOGM, bool STRIDED, bool INVERSE>
+static void pass_emu(const NttArgs &a, int gx, int gy)
+{
+#pragma omp parallel
+    {
+        std::vector<u64> lds(NTT_LDS_ELEMS);
+#pragma omp for collapse(2)
+        for (int by = 0; by < gy; by++)
+            for (int bx = 0; bx < gx; bx++) {
+                for (int t = 0; t < NTT_THREADS; t++) ntt_body_load<STRIDED, INVERSE>(a, bx, by, t, lds.data());
+                if constexpr (!INVERSE) rounds_fwd<LOGM, STRIDED, INVERSE, 0, 0>(a, bx, by, lds.data());
+                else rounds_inv<LOGM, STRIDED, INVERSE, NttSched<LOGM>::R - 1, LOGM>(a, bx, by, lds.data());
+                for (int t = 0; t < NTT_THREADS; t++) ntt_body_store<STRIDED, INVERSE>(a, bx, by, t, lds.data());
+            }
+    }
+}
+template <bool STRIDED, bool INVERSE>
+static void launch_pass(NttArgs a, int logm, int other)
+{
+    a.logm = logm;
+    int logc = NTT_TILE_LOG - logm;
+    if (logc > other) logc = other;
+    a.logc = logc;
+    const int gx = 1 << (other - logc), gy = a.count;
+    switch (logm) {
+    case 5: pass_emu<5, STRIDED, INVERSE>(a, gx, gy); break;
+    case 6: pass_emu<6, STRIDED, INVERSE>(a, gx, gy); break;
+    case 7: pass_emu<7, STRIDED, INVERSE>(a, gx, gy); break;
+    case 8: pass_emu<8, STRIDED, INVERSE>(a, gx, gy); break;
+    default: fprintf(stderr, "emu: unsupported pass size\n"); abort();
+    }
+}
+void k_ntt(const NttArgs &a, bool inverse, rt_stream)
+{
+    if (a.count <= 0) return;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    if (!inverse) { launch_pass<true, false>(a, n1, n2); launch_pass<false, false>(a, n2, n1); }
+    else { launch_pass<false, true>(a, n2, n1); launch_pass<true, true>(a, n1, n2); }
+}
+#define LOOP(total, call)                                         \
+    do {                                                          \
+        const long long _t = (long long)(total);                  \
+        _Pragma("omp parallel for") for (long long g = 0; g < _t; g++) { call; } \
+    } while (0)
+void k_elt(const EltArgs &a, int op, rt_stream) { LOOP((size_t)a.count << a.logn, elt_body(a, op, (size_t)g)); }
+void k_galois(const GaloisArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, galois_body(a, (size_t)g)); }
+void k_ks_mac(const KsMacArgs &a, rt_stream) { LOOP(((size_t)a.B * a.K) << a.logn, ks_mac_body(a, (size_t)g)); }
+void k_ks_finish(const KsFinishArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, ks_finish_body(a, (size_t)g)); }
+void k_add_plain(const AddPlainArgs &a, rt_stream) { LOOP((size_t)a.B << a.logn, add_plain_body(a, (size_t)g)); }
+void k_encode_scatter(const EncodeArgs &a, rt_stream) { LOOP((size_t)a.B * a.count * (a.second_off >= 0 ? 2 : 1), encode_scatter_body(a, (size_t)g)); }
+void k_diag(const DiagArgs &a, rt_stream) { LOOP((size_t)(PASTA_R + 1) * PASTA_T * 2 * PASTA_T, diag_body(a, (size_t)g)); }
+void k_behz_extend(const BehzExtendArgs &a, rt_stream) { LOOP((size_t)a.P << a.logn, behz_extend_body(a, (size_t)g)); }
+void k_tensor(const TensorArgs &a, rt_stream) { LOOP(((size_t)a.B * a.limbs) << a.logn, tensor_body(a, (size_t)g)); }
+void k_behz_floor(const BehzFloorArgs &a, rt_stream) { LOOP((size_t)a.P << a.logn, behz_floor_body(a, (size_t)g)); }

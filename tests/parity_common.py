@@ -1,0 +1,141 @@
+"""Parity checks shared by the CPU-emulator suite (numpy memory) and the GPU suite
+(torch cuda memory).  Every check compares the C-ABI library with the oracle bit for bit."""
+import numpy as np
+
+
+class HostMem:
+    """numpy-backed 'device' memory for the tests-only emulator."""
+
+    def to_dev(self, a):
+        return np.ascontiguousarray(a, dtype=np.uint64).copy()
+
+    def empty(self, shape):
+        return np.zeros(shape, np.uint64)
+
+    def to_host(self, b):
+        return np.array(b, copy=True)
+
+
+class TorchMem:
+    """torch cuda tensors (int64 storage viewed as uint64 words)."""
+
+    def __init__(self, device="cuda:0"):
+        import torch
+        self.torch, self.device = torch, device
+
+    def to_dev(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        return self.torch.from_numpy(a.view(np.int64)).to(self.device)
+
+    def empty(self, shape):
+        return self.torch.zeros(shape, dtype=self.torch.int64, device=self.device)
+
+    def to_host(self, b):
+        self.torch.cuda.synchronize()
+        return b.cpu().numpy().view(np.uint64)
+
+
+def check_context_constants(X, O):
+    for i in range(O.K):
+        assert X.query("root", i) == O.query("root", i)
+    for i in range(O.L + 1):
+        assert X.query("bsk", i) == O.query("bsk", i)
+    assert X.query("gamma") == O.query("gamma")
+    for s in (-1, 1, 128, -128, 0):
+        assert X.query("galois_elt", s) == O.galois_elt(s)
+    for j in range(O.L):
+        assert X.query("delta", j) == O.query("delta", j)
+
+
+def check_ntt(X, O, mem, seed=0):
+    rng = np.random.default_rng(seed)
+    nm = 2 * O.K  # coeff primes + Bsk primes
+    polys = np.stack([rng.integers(0, 1 << 40, O.n, dtype=np.uint64) for _ in range(nm + 1)])
+    polys[nm] %= O.t
+    ref = np.stack([O.ntt_fwd(i, polys[i]) for i in range(nm)] + [O.ntt_fwd(-1, polys[nm])])
+    d = mem.to_dev(polys)
+    X.ntt(d, nm + 1, 0, nm + 1, False)
+    assert (mem.to_host(d) == ref).all()
+    X.ntt(d, nm + 1, 0, nm + 1, True)
+    assert (mem.to_host(d) == polys).all()
+
+
+def check_ops(X, S, mem, B=3, seed=0):
+    """S: conftest.Setup with keys loaded into X."""
+    O = S.O
+    n, t = O.n, O.t
+    rng = np.random.default_rng(seed)
+    cts = np.stack([O.encrypt(S.pk, O.encode(rng.integers(0, t, n)), 10 + b) for b in range(B)])
+    d_cts = mem.to_dev(cts)
+    out = mem.empty(cts.shape)
+    # encode (ragged count)
+    vals = np.stack([rng.integers(0, t, 100, dtype=np.uint64) for _ in range(B)])
+    d_pl = mem.empty((B, n))
+    X.encode(mem.to_dev(vals), B, 100, d_pl)
+    pl = mem.to_host(d_pl)
+    for b in range(B):
+        assert (pl[b] == O.encode(vals[b])).all()
+    # add / negate
+    rev = cts[::-1].copy()
+    X.add(d_cts, mem.to_dev(rev), out, B)
+    h = mem.to_host(out)
+    for b in range(B):
+        assert (h[b] == O.add(cts[b], rev[b])).all()
+    X.negate(d_cts, out, B)
+    assert (mem.to_host(out)[0] == O.negate(cts[0])).all()
+    # add_plain / sub_plain / broadcast
+    X.add_plain(d_cts, d_pl, out, B)
+    h = mem.to_host(out)
+    for b in range(B):
+        assert (h[b] == O.add_plain(cts[b], pl[b])).all()
+    X.add_plain(d_cts, d_pl, out, B, subtract=True)
+    assert (mem.to_host(out)[1] == O.sub_plain(cts[1], pl[1])).all()
+    X.add_plain(d_cts, mem.to_dev(pl[0:1]), out, B, bcast=True)
+    assert (mem.to_host(out)[B - 1] == O.add_plain(cts[B - 1], pl[0])).all()
+    # multiply_plain
+    X.multiply_plain(d_cts, d_pl, out, B)
+    h = mem.to_host(out)
+    for b in range(B):
+        assert (h[b] == O.multiply_plain(cts[b], pl[b])).all()
+    X.multiply_plain(d_cts, mem.to_dev(pl[1:2]), out, B, bcast=True)
+    assert (mem.to_host(out)[B - 1] == O.multiply_plain(cts[B - 1], pl[1])).all()
+    # galois / rotations (incl. in place)
+    for e, k in zip(S.gk.elts, S.gk.keys):
+        X.apply_galois(d_cts, int(e), out, B)
+        h = mem.to_host(out)
+        for b in range(B):
+            assert (h[b] == O.apply_galois(cts[b], int(e), k)).all(), int(e)
+    x = mem.to_dev(cts)
+    X.rotate_rows(x, -1, x, B)
+    assert (mem.to_host(x)[1] == O.rotate_rows(cts[1], -1, S.gk)[0]).all()
+    X.rotate_columns(d_cts, out, B)
+    assert (mem.to_host(out)[0] == O.rotate_columns(cts[0], S.gk)).all()
+    # BEHZ multiply / square / relinearize
+    o3 = mem.empty((B, 3, O.L, n))
+    X.multiply(d_cts, mem.to_dev(rev), o3, B)
+    h3 = mem.to_host(o3)
+    for b in range(B):
+        assert (h3[b] == O.multiply(cts[b], rev[b])).all()
+    X.multiply(d_cts, d_cts, o3, B)
+    h3 = mem.to_host(o3)
+    assert (h3[1] == O.multiply(cts[1], cts[1])).all()
+    X.relinearize(o3, out, B)
+    assert (mem.to_host(out)[1] == O.relinearize(h3[1], S.rk)).all()
+
+
+def check_transcipher(X, S, orc, mem, pt, block_ids=None, check_decrypt=True, oracle_items=None):
+    """transcipher the PASTA encryption of pt; compare chosen items with the oracle bit for bit."""
+    O = S.O
+    cw, ncw = S.sym_blocks(orc, pt)
+    nb = cw.shape[0]
+    block_ids = list(range(nb)) if block_ids is None else block_ids
+    out = mem.empty((nb,) + O.ct_shape)
+    X.transcipher(mem.to_dev(S.enc_key), cw, ncw, block_ids, out)
+    res = mem.to_host(out)
+    for b in (range(nb) if oracle_items is None else oracle_items):
+        ref = O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], block_ids[b])
+        assert (res[b] == ref).all(), f"block {b} differs from oracle"
+        if check_decrypt:
+            dec = O.decode(O.decrypt(S.sk, res[b]))[:ncw[b]]
+            assert (dec == np.asarray(pt[b * 128:b * 128 + ncw[b]], dtype=np.uint64)).all()
+    return res

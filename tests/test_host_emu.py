@@ -1,0 +1,105 @@
+"""CPU checks of the PRODUCT's host driver (csrc/hhe_api.cpp, hhe_context.cpp, hhe_pasta_public.cpp) and
+of the kernel bodies' index arithmetic (csrc/hhe_kernel_bodies.h) through the tests-only emulator
+backend (tests/emu).  The emulator is test infrastructure; the product library has no CPU path."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import Setup
+import parity_common as pc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+T = 65537
+
+
+@pytest.fixture(scope="module")
+def mem():
+    return pc.HostMem()
+
+
+@pytest.mark.parametrize("logn,bits", [(10, [50] * 3), (11, [60] * 3), (12, [55] * 2), (13, [60] * 2), (14, [50] * 2), (15, [60] * 2)])
+def test_ntt_all_pass_sizes(orc, api, emu_lib, mem, logn, bits):
+    q = orc.coeff_modulus_create(1 << logn, bits)
+    O = orc.Oracle(logn, q, T)
+    X = api.Context(logn, q, T, lib=emu_lib)
+    assert b"emulator" in emu_lib.hhe_backend()
+    pc.check_context_constants(X, O)
+    pc.check_ntt(X, O, mem, seed=logn)
+
+
+def test_ntt_n65536_plain_modulus_33bit(orc, api, emu_lib, mem):
+    t = 8088322049  # configs/config.cpp:22 ; 65537 cannot batch at N=2^16
+    q = orc.coeff_modulus_create(1 << 16, [60, 60])
+    O = orc.Oracle(16, q, t)
+    X = api.Context(16, q, t, lib=emu_lib)
+    pc.check_ntt(X, O, mem, seed=16)
+
+
+def test_every_op_bit_exact(orc, api, emu_lib, mem, small):
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    small.load_keys(X)
+    pc.check_ops(X, small, mem, B=3)
+
+
+def test_ops_l8_exercises_lazy_accumulator_flush(orc, api, emu_lib, mem):
+    # L=5 > 4 limbs: the 128-bit lazy sums are flushed mid-way (ks_mac / BEHZ conversions)
+    S = Setup(orc, 10, [40] * 6)
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    pc.check_ops(X, S, mem, B=2, seed=5)
+
+
+def test_transcipher_ragged_blocks_bit_exact_and_decrypts(orc, api, emu_lib, mem, small):
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    small.load_keys(X)
+    pt = [(7 * i + 3) % 256 for i in range(300)]  # 3 blocks, last one ragged (44 words)
+    pc.check_transcipher(X, small, orc, mem, pt)
+
+
+def test_transcipher_same_block_counter_batch(orc, api, emu_lib, mem, small):
+    # BASELINE config 2 shape: independent 128-word inputs, all with block counter 0
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    small.load_keys(X)
+    O = small.O
+    B = 2
+    cw = np.zeros((B, 128), np.uint64)
+    for s in range(B):
+        x = np.array([(7 * i + 3 + s) % 256 for i in range(128)], dtype=np.uint64)
+        cw[s] = orc.pasta_encrypt(small.t, small.key, x)[:128]
+    out = mem.empty((B,) + O.ct_shape)
+    X.transcipher(mem.to_dev(small.enc_key), cw, [128] * B, [0] * B, out)
+    res = mem.to_host(out)
+    for s in range(B):
+        assert (res[s] == O.transcipher_block(small.enc_key, small.rk, small.gk, cw[s], 0)).all()
+        assert (O.decode(O.decrypt(small.sk, res[s]))[:128] == [(7 * i + 3 + s) % 256 for i in range(128)]).all()
+
+
+def test_missing_keys_and_bad_args_fail_loudly(orc, api, emu_lib, mem, small):
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    O = small.O
+    cw = np.zeros((1, 128), np.uint64)
+    out = mem.empty((1,) + O.ct_shape)
+    with pytest.raises(api.HheError) as e:
+        X.transcipher(mem.to_dev(small.enc_key), cw, [128], [0], out)
+    assert e.value.code == api.ERR_NO_RELIN_KEY
+    X.set_relin_key(small.rk)
+    with pytest.raises(api.HheError) as e:
+        X.transcipher(mem.to_dev(small.enc_key), cw, [128], [0], out)
+    assert e.value.code == api.ERR_NO_GALOIS_KEY and "Galois key not present" in str(e.value)
+    with pytest.raises(api.HheError):
+        X.rotate_rows(mem.to_dev(small.enc_key[None]), 5, out, 1)  # no key for 5 = naf{1,4}
+    with pytest.raises(api.HheError):
+        api.Context(10, [small.q[0], 12345], small.t, lib=emu_lib)  # not an NTT prime
+    with pytest.raises(api.HheError):
+        api.Context(10, small.q, 65539, lib=emu_lib)  # t not 1 mod 2N
+
+
+def test_product_block_randomness_matches_reference_golden(api, emu_lib):
+    g = json.load(open(os.path.join(HERE, "golden", "pasta_plain.json")))
+    for c in g["randomness"]:
+        mats, rcs = api.block_randomness(c["t"], c["block"], lib=emu_lib)
+        assert hashlib.sha256(mats.tobytes()).hexdigest() == c["mats_sha256"]
+        assert hashlib.sha256(rcs.tobytes()).hexdigest() == c["rcs_sha256"]
