@@ -47,6 +47,11 @@ def load_library(path=None):
         raise RuntimeError(
             f"{path} not found: the gfx950 HIP library is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    if os.path.abspath(path) == os.path.abspath(LIB_PATH):
+        # Device memory and streams are shared with PyTorch-ROCm, so both must sit on ONE HIP runtime:
+        # import torch first so libamdhip64.so.7 resolves to the copy torch already loaded (two HSA
+        # runtimes in one process cannot both open the GPU).
+        import torch  # noqa: F401
     lib = C.CDLL(path)
     for s in _SYMBOLS:
         getattr(lib, s)  # AttributeError if the ABI is incomplete

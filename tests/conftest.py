@@ -61,6 +61,7 @@ class Setup:
             for s in steps:
                 if O.galois_elt(s) not in elts:
                     elts.append(O.galois_elt(s))
+        elts = list(dict.fromkeys(int(e) for e in elts))  # SEAL keeps one key per element (get_elts_all repeats 3^(N/4))
         self.gk = O.keygen_galois(self.sk, elts, 7)
         self.key = np.array([(i * 2654435761 + 12345) % t for i in range(256)], dtype=np.uint64)
         self.enc_key = O.encrypt(self.pk, O.pasta_pack_key(self.key), 11)
