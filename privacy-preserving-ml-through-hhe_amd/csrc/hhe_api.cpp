@@ -30,6 +30,7 @@ NttArgs ntt_args(const hhe_ctx *c, const u64 *src, u64 *dst, size_t count, int m
     a.src = src; a.dst = dst; a.mods = c->d_mods; a.logn = c->logn; a.count = (int)count;
     a.mod_base = mod_base; a.mod_cycle = mod_cycle; a.src_div = 1; a.t = c->t;
     a.load_op = LOAD_PLAIN; a.store_op = STORE_PLAIN; a.mul_cycle = 1; a.mul_item_polys = 1;
+    a.L = c->L; a.K = c->K; a.ks = c->ksc;
     return a;
 }
 void op_ntt(hhe_ctx *c, u64 *polys, size_t count, int mod_base, int mod_cycle, bool inverse, int store_op = STORE_PLAIN)
@@ -239,6 +240,16 @@ int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
     op_lift_ntt(c, slots, ndiag, bt.diag);
     // round constants: rc1 -> slots [0,128), rc2 -> slots [N/2, N/2+128) (pasta_3_plain.cpp:286-295)
     op_encode(c, d_rcs, PASTA_R + 1, 2 * PASTA_T, PASTA_T, (int)half, bt.rc);
+    if (c->matmul_mode == 1) {
+        // pdiag = diag o pi_g for g = elt(rotate_rows -1): multiplier tables in the rotated NTT frame
+        bt.pdiag = (u64 *)rt_malloc(ndiag * L * n * 8);
+        if (!bt.pdiag) return dev_fail("block table alloc");
+        PermArgs p;
+        memset(&p, 0, sizeof(p));
+        p.in = bt.diag; p.out = bt.pdiag; p.mods = c->d_mods; p.logn = c->logn; p.count = (int)(ndiag * L); p.L = L;
+        p.out_item_stride = (size_t)L * n; p.elt = galois_elt_from_step(c, -1);
+        k_perm(p, c->stream);
+    }
     if (rt_sync(c->stream)) return dev_fail("block tables");
     rt_free(d_mats); rt_free(d_rcs); rt_free(slots);
     auto ins = c->blocks.emplace(block, bt);
@@ -272,6 +283,98 @@ int matmul_diagonal(hhe_ctx *c, int layer, const u64 *const *d_diag_ptrs, size_t
     }
     op_ntt(c, acc, B * 2 * L, 0, L, true);
     rt_d2d(state, acc, B * c->ct_words() * 8, c->stream);
+    return HHE_OK;
+}
+
+// PASTA_SEAL::diagonal (pasta_3_seal.cpp:370-413) as a fused pipeline: same ciphertext words as the
+// op-by-op schedule, 20 transforms per rotation step instead of 35 (DESIGN.md "fused matmul").
+//  - c0 stays in NTT form across the 127 rotate_rows(-1); c1 is kept in coefficient form because the
+//    key-switch digits need its canonical residues;
+//  - the 128 plain products are accumulated in the NTT domain, in the frame rotated by the Galois map
+//    (pdiag tables), so the NTT of galois(c1) computed for the key switch is reused for the product;
+//  - mod-down of c0 is finished in the NTT domain: NTT_j(r_0 mod q_j - half) replaces INTT+NTT.
+int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs, size_t B)
+{
+    const int L = c->L, K = c->K;
+    const size_t n = c->n, ln = (size_t)L * n, bln = B * ln;
+    u64 *state = c->ws_ct[0];
+    if (n / 2 != PASTA_T) {
+        int rc = op_rotate_rows(c, state, PASTA_T, c->ws_ct[2], B);
+        if (rc) return rc;
+        op_add(c, state, c->ws_ct[2], state, B, 2);
+    }
+    const u32 g = galois_elt_from_step(c, -1);
+    auto it = c->d_gk.find(g);
+    if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    const u64 *key = it->second;
+    const u32 ginv = (u32)nt_invmod(g, 2 * n);
+    u64 *accp0 = c->ws_ct[1], *accp1 = c->ws_ct[1] + bln;
+    u64 *c0n[2] = {c->ws_ct[2], c->ws_ct[2] + bln};
+    u64 *scr = c->ws_ct[3], *r = c->ws_ct[3] + bln;
+    rt_memset(c->ws_ct[1], 0, 2 * bln * 8, c->stream);
+    {   // c0 -> NTT form ; d = galois(c1)
+        NttArgs a = ntt_args(c, state, c0n[0], B * L, 0, L);
+        a.src_item_polys = L; a.src_item_stride = 2 * ln;
+        k_ntt(a, false, c->stream);
+        GaloisArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.mods = c->d_mods; ga.logn = c->logn; ga.count = (int)(B * L); ga.L = L; ga.einv = ginv;
+        ga.in = state + ln; ga.in_item_stride = 2 * ln; ga.out = c->ws_d; ga.out_item_stride = ln;
+        k_galois(ga, c->stream);
+    }
+    int cur = 0;
+    for (int i = 0; i < PASTA_T - 1; ++i) {
+        const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
+        {   // digits: T[I][J] = NTT_J(d[I] mod q_J); diagonal digits feed the plain product
+            NttArgs a = ntt_args(c, c->ws_d, c->ws_T, B * L * K, 0, K);
+            a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT;
+            a.store_op = STORE_DIGIT_DIAG; a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.acc = accp1;
+            k_ntt(a, false, c->stream);
+        }
+        {
+            KsMacArgs m;
+            memset(&m, 0, sizeof(m));
+            m.T = c->ws_T; m.key = key; m.S = c->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
+            k_ks_mac(m, c->stream);
+        }
+        {   // r_k = INTT(S_k[special]) + floor(q_sp/2)
+            NttArgs a = ntt_args(c, c->ws_S + (size_t)(K - 1) * n, r, B * 2, K - 1, 1);
+            a.src_item_polys = 1; a.src_item_stride = (size_t)K * n; a.store_op = STORE_RSP;
+            k_ntt(a, true, c->stream);
+        }
+        {   // c1 of the next state, coefficient form, already passed through the Galois map for the next digits
+            NttArgs a = ntt_args(c, c->ws_S + (size_t)K * n, scr, B * L, 0, L);
+            a.src_item_polys = L; a.src_item_stride = (size_t)2 * K * n; a.store_op = STORE_KS1;
+            a.aux_r = r; a.aux_out = c->ws_d; a.gal_elt = g;
+            k_ntt(a, true, c->stream);
+        }
+        {   // c0 of the next state in NTT form + permuted-frame product of the current c0
+            NttArgs a = ntt_args(c, r, scr, B * L, 0, L);
+            a.src_item_polys = L; a.src_item_stride = 2 * n; a.src_div = L; a.load_op = LOAD_RNEG;
+            a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.aux_r = c->ws_S; a.acc = accp0;
+            a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g;
+            k_ntt(a, false, c->stream);
+        }
+        cur ^= 1;
+    }
+    const size_t shift = ((size_t)layer * PASTA_T + (PASTA_T - 1)) * ln;
+    {   // last state: products only (a "virtual" rotation keeps the frame uniform)
+        NttArgs a = ntt_args(c, c->ws_d, scr, B * L, 0, L);
+        a.store_op = STORE_MAC; a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.mul_cycle = L; a.mul_item_polys = L; a.acc = accp1;
+        k_ntt(a, false, c->stream);
+        PermArgs p;
+        memset(&p, 0, sizeof(p));
+        p.in = c0n[cur]; p.out = accp0; p.mods = c->d_mods; p.logn = c->logn; p.count = (int)(B * L); p.L = L;
+        p.out_item_stride = ln; p.elt = g; p.mac = 1; p.mul_ptrs = d_pdiag_ptrs; p.mul_shift = shift;
+        k_perm(p, c->stream);
+        // back to the unrotated frame, then to coefficient form
+        p.mac = 0; p.mul_ptrs = nullptr; p.elt = ginv; p.out_item_stride = 2 * ln;
+        p.in = accp0; p.out = state;
+        k_perm(p, c->stream);
+        p.in = accp1; p.out = state + ln;
+        k_perm(p, c->stream);
+    }
+    op_ntt(c, state, B * 2 * L, 0, L, true);
     return HHE_OK;
 }
 
@@ -383,12 +486,13 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
     if ((rc = ensure_feistel_mask(c))) return rc;
     // per-item public tables
     std::vector<const u64 *> diag_ptrs(B), rc_ptrs(B);
+    const bool fused = c->matmul_mode == 1;
     std::vector<u64> cwp(B * PASTA_T, 0);
     for (size_t b = 0; b < B; ++b) {
         if (ncw[b] > PASTA_T) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: more than 128 words in a block");
         BlockTables *bt = nullptr;
         if ((rc = ensure_block(c, block_index[b], &bt))) return rc;
-        diag_ptrs[b] = bt->diag; rc_ptrs[b] = bt->rc;
+        diag_ptrs[b] = fused ? bt->pdiag : bt->diag; rc_ptrs[b] = bt->rc;
         memcpy(&cwp[b * PASTA_T], cw + b * PASTA_T, ncw[b] * 8);
     }
     const u64 **d_ptrs = (const u64 **)rt_malloc(2 * B * sizeof(u64 *));
@@ -401,7 +505,7 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
     // state <- enc_ssk[0] for every item (pasta_3_seal.cpp:126)
     op_elt(c, ELT_BCAST, nullptr, enc_key, state, B * 2 * L, 0, L, 2 * L);
     for (int r = 0; r <= PASTA_R && !rc; ++r) {
-        if ((rc = matmul_diagonal(c, r, d_ptrs, B))) break;
+        if ((rc = fused ? matmul_diagonal_fused(c, r, d_ptrs, B) : matmul_diagonal(c, r, d_ptrs, B))) break;
         // add_rc (:205-211)
         op_add_plain(c, state, nullptr, d_ptrs + B, (size_t)r * n, false, false, false, state, B);
         // mix (:417-423)

@@ -32,8 +32,22 @@ struct ModDev {
 // Modulus indices inside ModDev[]: 0..K-1 coefficient primes (K-1 = special),
 // K..K+L Bsk = {B_0..B_{L-1}, m_sk}, K+L+1 = plain modulus t.
 
-enum NttLoadOp { LOAD_PLAIN = 0, LOAD_DIGIT = 1, LOAD_LIFT = 2 };
-enum NttStoreOp { STORE_PLAIN = 0, STORE_MUL = 1, STORE_SCALE_T = 2, STORE_MAC = 3 };
+enum NttLoadOp { LOAD_PLAIN = 0, LOAD_DIGIT = 1, LOAD_LIFT = 2, LOAD_RNEG = 3 };
+enum NttStoreOp {
+    STORE_PLAIN = 0, STORE_MUL = 1, STORE_SCALE_T = 2, STORE_MAC = 3,
+    STORE_DIGIT_DIAG = 4,  // fwd: keep T; polys with J == I also accumulate T * permD into aux_acc
+    STORE_RSP = 5,         // inv (special limb): v + floor(q_sp/2) mod q_sp
+    STORE_KS1 = 6,         // inv: (v - r_1 + half) * q_sp^-1, written through the Galois map into aux_out
+    STORE_KS0 = 7          // fwd: NTT-domain key-switch finish of c0 + permuted-frame diagonal MAC
+};
+
+// key-switch mod-down constants, passed by value to the kernels that finish a key switch
+struct KsConsts {
+    u64 half;                 // floor(q_sp/2)
+    u64 half_mod[HHE_MAXL];   // half mod q_j
+    u64 qsp_inv[HHE_MAXL];    // q_sp^-1 mod q_j
+    u64 qsp_inv_s[HHE_MAXL];
+};
 
 struct NttArgs {
     const u64 *src;
@@ -56,7 +70,14 @@ struct NttArgs {
     const u64 *const *mul_ptrs;
     size_t mul_shift;
     int mul_cycle, mul_item_polys;
-    u64 *acc;       // STORE_MAC: acc[p][i] += NTT(x)[i] * mul
+    u64 *acc;       // STORE_MAC / DIGIT_DIAG / KS0: accumulator polys
+    // fused key-switch epilogues (matmul pipeline)
+    int L, K;
+    u32 gal_elt;        // KS1: coefficient-domain Galois element (0 = identity); KS0: NTT-domain element
+    const u64 *aux_r;   // KS1: r [B][2][N] (poly 1 used);  KS0: S [B][2][K][N] (poly 0, limb j)
+    const u64 *aux_in;  // KS0: c0 (NTT form) of the current state [B][L][N]
+    u64 *aux_out;       // KS1: d [B][L][N];  KS0: c0 (NTT form) of the next state [B][L][N]
+    KsConsts ks;
 };
 
 enum EltOp { ELT_ADD = 0, ELT_SUB = 1, ELT_NEG = 2, ELT_MUL = 3, ELT_MAC = 4, ELT_COPY = 5, ELT_BCAST = 6 };
@@ -84,6 +105,18 @@ struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
     u64 *S;          // [B][2][K][N]
     const ModDev *mods;
     int logn, B, L, K;
+};
+
+struct PermArgs {  // NTT-domain Galois permutation: out[p][x] (op)= in[p][pi_elt(x)] (* mul)
+    const u64 *in;
+    u64 *out;
+    const ModDev *mods;
+    int logn, count, L;        // poly p = (item b, limb j)
+    size_t out_item_stride;    // words between items in out (in is [count][N])
+    u32 elt;
+    int mac;                   // 1: out[p][x] += in[p][pi(x)] * mul_ptrs[b][shift + j*N + x]
+    const u64 *const *mul_ptrs;
+    size_t mul_shift;
 };
 
 struct KsFinishArgs {  // SURVEY A.4 mod-down; S already INTT'd (coefficient form)

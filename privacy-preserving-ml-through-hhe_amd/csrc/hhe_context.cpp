@@ -268,6 +268,9 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
         hhe_ctx_destroy(c);
         return HHE_ERR_DEVICE;
     }
+    c->ksc.half = kf.half;
+    for (int j = 0; j < L; ++j) { c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j]; }
+    if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
     kf.mods = c->d_mods; kf.logn = logn; kf.L = L; kf.K = K;
     ap.mods = c->d_mods; ap.logn = logn; ap.L = L;
     *out = c;
@@ -288,7 +291,7 @@ extern "C" void hhe_pasta3_clear_block_cache(hhe_ctx *c)
 {
     if (!c) return;
     rt_sync(c->stream);
-    for (auto &kv : c->blocks) { rt_free(kv.second.diag); rt_free(kv.second.rc); rt_free(kv.second.bsgs); }
+    for (auto &kv : c->blocks) { rt_free(kv.second.diag); rt_free(kv.second.pdiag); rt_free(kv.second.rc); rt_free(kv.second.bsgs); }
     c->blocks.clear();
 }
 

@@ -9,6 +9,7 @@
 struct BlockTables {   // public per-(nonce, block index) data of one PASTA block, device resident
     u64 *diag = nullptr;  // [4][128][L][N] lifted + NTT'd diagonals (multiply_plain operands)
     u64 *rc = nullptr;    // [4][N] round-constant plaintexts (coefficients mod t)
+    u64 *pdiag = nullptr; // diag composed with the NTT-domain index map of rotate_rows(-1): pdiag[x] = diag[pi(x)]
     u64 *bsgs = nullptr;  // [4][128][L][N] babystep-giantstep variant of diag (lazy)
 };
 
@@ -23,6 +24,8 @@ struct hhe_ctx {
     int nmod = 0;                  // K + (L+1) + 1
     int mod_t = 0;                 // index of the plain modulus
     rt_stream stream = nullptr;
+    int matmul_mode = 1;           // 1: fused 20-transform pipeline (default), 0: op-by-op schedule
+    KsConsts ksc{};
 
     // device tables
     ModDev *d_mods = nullptr;

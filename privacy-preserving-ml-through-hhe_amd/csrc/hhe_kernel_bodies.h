@@ -22,6 +22,25 @@ template <> struct NttSched<6> { static constexpr int R = 2; static constexpr in
 template <> struct NttSched<7> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 4 : 3; } };
 template <> struct NttSched<8> { static constexpr int R = 2; static constexpr int rho(int i) { return 4; } };
 
+HD u32 bitrev_n(u32 v, int bits)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v) >> (32 - bits);
+#else
+    u32 r = 0;
+    for (int i = 0; i < bits; i++) { r = (r << 1) | (v & 1); v >>= 1; }
+    return r;
+#endif
+}
+// index map of a Galois automorphism in SEAL's (bit-reversed) NTT domain (seal/util/galois.h:143-153):
+// NTT(galois_elt(a))[x] = NTT(a)[ntt_perm_index(x)]
+HD u32 ntt_perm_index(u32 x, int logn, u32 elt)
+{
+    const u32 e = 2 * bitrev_n(x, logn) + 1;
+    const u32 e2 = (u32)(((u64)e * elt) & ((2u << logn) - 1));
+    return bitrev_n((e2 - 1) >> 1, logn);
+}
+
 struct NttGeom {
     int n, M, C, pitch, N_over_M;
     int poly, mod_index, tile;
@@ -66,6 +85,7 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
         if (FIRST) {
             if (a.load_op == LOAD_DIGIT) v = reduce64(v, m);
             else if (a.load_op == LOAD_LIFT) v = (v >= ((a.t + 1) >> 1)) ? v + (m.q - a.t) : v;
+            else if (a.load_op == LOAD_RNEG) v = submod(reduce64(v, m), a.ks.half_mod[g.poly % a.L], m.q);
         }
         lds[x * g.pitch + lane] = v;
     }
@@ -156,6 +176,22 @@ HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds
                 if (a.store_op == STORE_SCALE_T) v = shoup_lazy(v, m.ninv_t, m.ninv_t_s, q);
                 else v = shoup_lazy(v, m.ninv, m.ninv_s, q);
                 v -= (v >= q) ? q : 0;
+                if (a.store_op == STORE_RSP) v = addmod(v, a.ks.half, q);
+                else if (a.store_op == STORE_KS1) {
+                    const int j = g.poly % a.L;
+                    const size_t item = g.poly / a.L;
+                    const u64 rj = reduce64(a.aux_r[(item * 2 + 1) * g.n + gi], m);
+                    v = addmod(submod(v, rj, q), a.ks.half_mod[j], q);
+                    v = shoup_mul(v, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
+                    u32 idx = (u32)gi;
+                    if (a.gal_elt) {
+                        const u64 raw = (u64)gi * a.gal_elt;
+                        idx = (u32)(raw & (g.n - 1));
+                        if ((raw >> a.logn) & 1) v = negmod(v, q);
+                    }
+                    a.aux_out[(size_t)g.poly * g.n + idx] = v;
+                    continue;
+                }
             } else {
                 v -= (v >= q2) ? q2 : 0;
                 v -= (v >= q) ? q : 0;
@@ -167,6 +203,26 @@ HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds
                         *ap = addmod(*ap, v, q);
                         continue;
                     }
+                } else if (a.store_op == STORE_DIGIT_DIAG) {
+                    const int J = g.poly % a.K, I = (g.poly / a.K) % a.L;
+                    if (I == J) {
+                        const size_t item = g.poly / (a.K * a.L);
+                        const u64 d = a.mul_ptrs[item][a.mul_shift + (size_t)I * g.n + gi];
+                        u64 *ap = a.acc + (item * a.L + I) * g.n + gi;
+                        *ap = addmod(*ap, mulmod(v, d, m), q);
+                    }
+                } else if (a.store_op == STORE_KS0) {
+                    const int j = g.poly % a.L;
+                    const size_t item = g.poly / a.L;
+                    const u32 pi = ntt_perm_index((u32)gi, a.logn, a.gal_elt);
+                    const u64 gth = a.aux_in[(size_t)g.poly * g.n + pi];
+                    const u64 d = a.mul_ptrs[item][a.mul_shift + (size_t)j * g.n + gi];
+                    u64 *ap = a.acc + (size_t)g.poly * g.n + gi;
+                    *ap = addmod(*ap, mulmod(gth, d, m), q);
+                    const u64 s0 = a.aux_r[((item * 2 + 0) * a.K + j) * g.n + gi];
+                    const u64 o = shoup_mul(submod(s0, v, q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
+                    a.aux_out[(size_t)g.poly * g.n + gi] = addmod(gth, o, q);
+                    continue;
                 }
             }
         }
@@ -211,6 +267,21 @@ HD void galois_body(const GaloisArgs &a, size_t gid)
     const u64 *src = a.in + item * a.in_item_stride + limb * n;
     u64 v = (j < n) ? src[j] : negmod(src[j - n], q);
     a.out[item * a.out_item_stride + limb * n + k] = v;
+}
+
+// NTT-domain Galois gather, optionally multiply-accumulating with a per-item table: gid over [count][N]
+HD void perm_body(const PermArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t p = gid >> a.logn;
+    if (p >= (size_t)a.count) return;
+    const u32 x = (u32)(gid & (n - 1));
+    const size_t item = p / a.L, j = p % a.L;
+    const ModDev &m = a.mods[j];
+    const u64 v = a.in[p * n + ntt_perm_index(x, a.logn, a.elt)];
+    u64 *o = a.out + item * a.out_item_stride + j * n + x;
+    if (a.mac) *o = addmod(*o, mulmod(v, a.mul_ptrs[item][a.mul_shift + j * n + x], m), m.q);
+    else *o = v;
 }
 
 // key-switch inner product: gid over [B][K][N]

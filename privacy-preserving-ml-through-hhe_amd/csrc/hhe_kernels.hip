@@ -108,6 +108,7 @@ static inline unsigned nblocks(size_t total) { return (unsigned)((total + ELT_TH
 
 __global__ void __launch_bounds__(ELT_THREADS) elt_kernel(EltArgs a, int op) { elt_body(a, op, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) galois_kernel(GaloisArgs a) { galois_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) perm_kernel(PermArgs a) { perm_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_mac_kernel(KsMacArgs a) { ks_mac_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_finish_kernel(KsFinishArgs a) { ks_finish_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) add_plain_kernel(AddPlainArgs a) { add_plain_body(a, GID); }
@@ -125,6 +126,7 @@ __global__ void __launch_bounds__(ELT_THREADS) behz_floor_kernel(BehzFloorArgs a
 
 void k_elt(const EltArgs &a, int op, rt_stream s) { LAUNCH1D(elt_kernel, (size_t)a.count << a.logn, s, a, op); }
 void k_galois(const GaloisArgs &a, rt_stream s) { LAUNCH1D(galois_kernel, (size_t)a.count << a.logn, s, a); }
+void k_perm(const PermArgs &a, rt_stream s) { LAUNCH1D(perm_kernel, (size_t)a.count << a.logn, s, a); }
 void k_ks_mac(const KsMacArgs &a, rt_stream s) { LAUNCH1D(ks_mac_kernel, ((size_t)a.B * a.K) << a.logn, s, a); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream s) { LAUNCH1D(ks_finish_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
 void k_add_plain(const AddPlainArgs &a, rt_stream s) { LAUNCH1D(add_plain_kernel, (size_t)a.B << a.logn, s, a); }

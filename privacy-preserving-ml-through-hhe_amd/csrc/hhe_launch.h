@@ -22,6 +22,7 @@ const char *rt_last_error();
 void k_ntt(const NttArgs &a, bool inverse, rt_stream s);  // runs both passes; a.logm/logc ignored
 void k_elt(const EltArgs &a, int op, rt_stream s);
 void k_galois(const GaloisArgs &a, rt_stream s);
+void k_perm(const PermArgs &a, rt_stream s);
 void k_ks_mac(const KsMacArgs &a, rt_stream s);
 void k_ks_finish(const KsFinishArgs &a, rt_stream s);
 void k_add_plain(const AddPlainArgs &a, rt_stream s);

@@ -103,3 +103,19 @@ def test_product_block_randomness_matches_reference_golden(api, emu_lib):
         mats, rcs = api.block_randomness(c["t"], c["block"], lib=emu_lib)
         assert hashlib.sha256(mats.tobytes()).hexdigest() == c["mats_sha256"]
         assert hashlib.sha256(rcs.tobytes()).hexdigest() == c["rcs_sha256"]
+
+
+def test_fused_matmul_equals_op_by_op_schedule(orc, api, emu_lib, mem, small, monkeypatch):
+    """the 20-transform fused diagonal pipeline and the literal op-by-op schedule give the same words"""
+    pt = [(11 * i + 5) % 256 for i in range(128)]
+    cw, ncw = small.sym_blocks(orc, pt)
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HHE_MATMUL", mode)
+        X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+        small.load_keys(X)
+        out = mem.empty((1,) + small.O.ct_shape)
+        X.transcipher(mem.to_dev(small.enc_key), cw, ncw, [5], out)
+        outs.append(mem.to_host(out))
+    assert (outs[0] == outs[1]).all()
+    assert (outs[0][0] == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[0], 5)).all()
