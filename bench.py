@@ -151,7 +151,7 @@ def main():
         if world == 1 and args.cpu_baseline:
             import oracle as orc  # CPU baseline leg only
             O = orc.Oracle(LOGN, q, t)
-            threads = os.cpu_count() or 1
+            threads = min(16, len(os.sched_getaffinity(0)))  # the GPU box grants 16 cores per GPU
             nb = threads * args.cpu_blocks_per_thread
             elts = sorted(gks)
             gk = orc.GaloisKeys(elts, np.stack([gks[e] for e in elts]))

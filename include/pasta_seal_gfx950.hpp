@@ -1,0 +1,234 @@
+// pasta_seal_gfx950.hpp -- C++ host-side mirror of the reference's cipher-layer interface for the
+// CSP hot path, implemented over the C ABI of libhhe_gfx950.so (include/hhe_gfx950.h).
+//
+// Mirrors (same names, argument meaning and error behaviour):
+//   pasta::SEALZpCipher   src/pasta/SEAL_Cipher.h:11-129   (get_plain_size, mask, flatten, activate_bsgs, ...)
+//   pasta::PASTA_SEAL     src/pasta/pasta_3_seal.h:8-54    (HE_decrypt, decomposition, add_gk_indices, ...)
+//   sealhelper::packed_enc_multiply / encrypted_vec_sum   src/util/sealhelper.h:84-129
+// The reference passes seal:: objects; SEAL is not linked here, so the boundary types below are plain
+// word containers with SEAL's in-memory layouts (what Ciphertext::data(), KSwitchKeys::data() hold).
+// INTEGRATION.md shows the 1:1 conversion a SEAL-linking caller adds.  Errors surface as the C++
+// exceptions the reference / SEAL throw (std::runtime_error, std::invalid_argument, std::logic_error).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "hhe_gfx950.h"
+
+namespace pasta {
+
+struct ZpCipherParams {  // src/pasta/Cipher.h:14-18
+    size_t key_size, plain_size, cipher_size;
+};
+constexpr ZpCipherParams PASTA_PARAMS = {256, 128, 128};  // src/pasta/pasta_3_plain.h:15
+
+// seal::Ciphertext stand-in: data() words, [size][L][N], data level, non-NTT form
+struct Ciphertext {
+    std::vector<uint64_t> words;
+    size_t size = 0;
+};
+// one KSwitchKeys::data()[index] entry: [L digits][2][K][N], NTT form
+typedef std::vector<uint64_t> KSwitchKey;
+struct RelinKeys { KSwitchKey key; };                       // RelinKeys::key(2)
+struct GaloisKeys { std::map<uint32_t, KSwitchKey> keys; }; // by Galois element (GaloisKeys::get_index = (elt-1)/2)
+struct PublicKey { std::vector<uint64_t> words; };          // unused on the CSP path (kept for signature parity)
+struct SecretKey { std::vector<uint64_t> words; };
+
+// seal::SEALContext stand-in: (N, coeff_modulus incl. the special prime, plain_modulus)
+class HheContext {
+public:
+    HheContext(int logn, std::vector<uint64_t> coeff_modulus, uint64_t plain_modulus, int device = 0)
+        : logn_(logn), q_(std::move(coeff_modulus)), t_(plain_modulus)
+    {
+        if (hhe_ctx_create(logn, (int)q_.size(), q_.data(), t_, device, &h_) != HHE_OK)
+            throw std::invalid_argument(std::string("encryption parameters are not set correctly: ") + hhe_last_error());
+    }
+    ~HheContext() { hhe_ctx_destroy(h_); }
+    HheContext(const HheContext &) = delete;
+    HheContext &operator=(const HheContext &) = delete;
+    hhe_ctx *handle() const { return h_; }
+    size_t poly_modulus_degree() const { return (size_t)1 << logn_; }
+    size_t data_limbs() const { return q_.size() - 1; }
+    size_t ct_words() const { return 2 * data_limbs() * poly_modulus_degree(); }
+    uint64_t plain_modulus() const { return t_; }
+
+private:
+    int logn_;
+    std::vector<uint64_t> q_;
+    uint64_t t_;
+    hhe_ctx *h_ = nullptr;
+};
+
+namespace detail {
+inline void check(int rc)
+{
+    if (rc == HHE_OK) return;
+    const std::string msg = hhe_last_error();
+    switch (rc) {
+    case HHE_ERR_TOO_FEW_SLOTS: throw std::runtime_error(msg);   // pasta_3_seal.cpp:376-377
+    case HHE_ERR_NO_GALOIS_KEY:
+    case HHE_ERR_INVALID: throw std::invalid_argument(msg);      // SEAL: invalid_argument
+    case HHE_ERR_NO_RELIN_KEY: throw std::invalid_argument(msg);
+    default: throw std::runtime_error(msg);
+    }
+}
+struct DevBuf {  // RAII device buffer
+    void *p = nullptr;
+    explicit DevBuf(size_t bytes) : p(hhe_malloc(bytes)) { if (!p) throw std::runtime_error("hhe_malloc failed"); }
+    ~DevBuf() { hhe_free(p); }
+    DevBuf(const DevBuf &) = delete;
+    uint64_t *u64() const { return (uint64_t *)p; }
+};
+}  // namespace detail
+
+class SEALZpCipher {
+public:
+    typedef std::vector<uint64_t> vector;
+
+    SEALZpCipher(ZpCipherParams params, std::shared_ptr<HheContext> con, PublicKey pk, SecretKey sk, RelinKeys rk, GaloisKeys gk)
+        : params(params), context(std::move(con)), he_pk(std::move(pk)), he_sk(std::move(sk))
+    {
+        hhe_ctx *h = context->handle();
+        if (!rk.key.empty()) detail::check(hhe_set_relin_key(h, rk.key.data()));
+        for (auto &kv : gk.keys) detail::check(hhe_set_galois_key(h, kv.first, kv.second.data()));
+        mod_degree = context->poly_modulus_degree();
+        plain_mod = context->plain_modulus();
+    }
+    virtual ~SEALZpCipher() = default;
+
+    size_t get_key_size() const { return params.key_size; }
+    size_t get_plain_size() const { return params.plain_size; }
+    size_t get_cipher_size() const { return params.cipher_size; }
+    virtual std::string get_cipher_name() const = 0;
+    virtual std::vector<Ciphertext> HE_decrypt(std::vector<uint64_t> &ciphertext, bool batch_encoder = false) = 0;
+    virtual void add_gk_indices() = 0;
+
+    void activate_bsgs(bool activate) { use_bsgs = activate; }
+    void set_bsgs_params(uint64_t n1, uint64_t n2) { bsgs_n1 = n1; bsgs_n2 = n2; }
+    void add_some_gk_indices(std::vector<int> &gk_ind) { for (int i : gk_ind) gk_indices.push_back(i); }
+    const std::vector<int> &get_gk_indices() const { return gk_indices; }
+
+    // SEALZpCipher::mask (SEAL_Cipher.cpp:161-166)
+    void mask(Ciphertext &cipher, std::vector<uint64_t> &mask_vec)
+    {
+        detail::DevBuf d(cipher.words.size() * 8);
+        hhe_ctx *h = context->handle();
+        detail::check(hhe_copy_h2d(h, d.p, cipher.words.data(), cipher.words.size() * 8));
+        detail::check(hhe_mask(h, d.u64(), mask_vec.data(), mask_vec.size(), d.u64(), 1));
+        detail::check(hhe_copy_d2h(h, cipher.words.data(), d.p, cipher.words.size() * 8));
+    }
+    // SEALZpCipher::flatten (SEAL_Cipher.cpp:170-181); uses the Galois keys held by this object
+    void flatten(std::vector<Ciphertext> &in, Ciphertext &out)
+    {
+        if (in.empty()) throw std::invalid_argument("flatten: empty input");
+        const size_t w = context->ct_words();
+        detail::DevBuf d(in.size() * w * 8), o(w * 8);
+        hhe_ctx *h = context->handle();
+        for (size_t i = 0; i < in.size(); i++) detail::check(hhe_copy_h2d(h, d.u64() + i * w, in[i].words.data(), w * 8));
+        detail::check(hhe_flatten(h, d.u64(), in.size(), o.u64(), 1));
+        out.words.resize(w);
+        out.size = 2;
+        detail::check(hhe_copy_d2h(h, out.words.data(), o.p, w * 8));
+    }
+
+protected:
+    ZpCipherParams params;
+    uint64_t plain_mod = 0, mod_degree = 0;
+    std::vector<Ciphertext> secret_key_encrypted;
+    std::shared_ptr<HheContext> context;
+    PublicKey he_pk;
+    SecretKey he_sk;
+    std::vector<int> gk_indices;
+    bool use_bsgs = false;
+    size_t bsgs_n1 = 0, bsgs_n2 = 0;
+};
+
+class PASTA_SEAL : public SEALZpCipher {
+public:
+    PASTA_SEAL(std::shared_ptr<HheContext> con, PublicKey pk, SecretKey sk, RelinKeys rk, GaloisKeys gk)
+        : SEALZpCipher(PASTA_PARAMS, std::move(con), std::move(pk), std::move(sk), std::move(rk), std::move(gk)),
+          slots(mod_degree), halfslots(mod_degree >> 1) {}
+
+    virtual std::string get_cipher_name() const { return "PASTA-SEAL (n=128,r=3)"; }
+
+    // pasta_3_seal.cpp:190-201
+    virtual void add_gk_indices()
+    {
+        gk_indices.push_back(0);
+        gk_indices.push_back(-1);
+        if (PASTA_PARAMS.plain_size * 2 != slots) gk_indices.push_back((int)PASTA_PARAMS.plain_size);
+        if (use_bsgs)
+            for (uint64_t k = 1; k < BSGS_N2; k++) gk_indices.push_back(-(int)(k * BSGS_N1));
+    }
+
+    // supply the BFV encryption of the PASTA key that HE_decrypt reads (secret_key_encrypted[0],
+    // pasta_3_seal.cpp:58; filled by encrypt_key() on the client side of the reference)
+    void set_encrypted_key(const Ciphertext &enc_key) { secret_key_encrypted.assign(1, enc_key); }
+
+    // PASTA_SEAL::HE_decrypt (pasta_3_seal.cpp:42-104) == decomposition(ciphertexts, secret_key_encrypted)
+    virtual std::vector<Ciphertext> HE_decrypt(std::vector<uint64_t> &ciphertexts, bool batch_encoder = false)
+    {
+        if (secret_key_encrypted.empty()) throw std::logic_error("HE_decrypt: encrypted key not set");
+        return decomposition(ciphertexts, secret_key_encrypted, batch_encoder);
+    }
+
+    // PASTA_SEAL::decomposition (pasta_3_seal.cpp:106-172)
+    virtual std::vector<Ciphertext> decomposition(std::vector<uint64_t> &ciphertexts, std::vector<Ciphertext> enc_ssk,
+                                                  bool batch_encoder = false)
+    {
+        (void)batch_encoder;  // ignored by the reference as well (:113)
+        if (enc_ssk.empty()) throw std::invalid_argument("decomposition: enc_ssk is empty");
+        const size_t size = ciphertexts.size();
+        const size_t num_block = (size_t)std::ceil((double)size / (double)params.cipher_size);
+        std::vector<Ciphertext> res(num_block);
+        if (num_block == 0) return res;
+        const size_t w = context->ct_words();
+        hhe_ctx *h = context->handle();
+        std::vector<uint64_t> cw(num_block * 128, 0), bidx(num_block);
+        std::vector<uint32_t> ncw(num_block);
+        for (size_t b = 0; b < num_block; b++) {
+            const size_t lo = b * params.cipher_size, hi = std::min(lo + params.cipher_size, size);
+            for (size_t i = lo; i < hi; i++) cw[b * 128 + (i - lo)] = ciphertexts[i];
+            ncw[b] = (uint32_t)(hi - lo);
+            bidx[b] = b;
+        }
+        detail::DevBuf key(w * 8), out(num_block * w * 8);
+        if (enc_ssk[0].words.size() != w) throw std::invalid_argument("decomposition: enc_ssk is not valid for encryption parameters");
+        detail::check(hhe_copy_h2d(h, key.p, enc_ssk[0].words.data(), w * 8));
+        detail::check(hhe_pasta3_transcipher(h, key.u64(), cw.data(), ncw.data(), bidx.data(), num_block, use_bsgs ? 1 : 0, out.u64()));
+        for (size_t b = 0; b < num_block; b++) {
+            res[b].words.resize(w);
+            res[b].size = 2;
+            detail::check(hhe_copy_d2h(h, res[b].words.data(), out.u64() + b * w, w * 8));
+        }
+        return res;
+    }
+
+private:
+    static constexpr uint64_t BSGS_N1 = 16, BSGS_N2 = 8;  // pasta_3_seal.h:35-36
+    size_t slots, halfslots;
+};
+
+}  // namespace pasta
+
+namespace sealhelper {
+// packed_enc_multiply + relinearize + encrypted_vec_sum for one weight row (sealhelper.cpp:268-274,379-392; CSP.cpp:306)
+inline void fc_row(pasta::HheContext &ctx, const pasta::Ciphertext &vi, const pasta::Ciphertext &w_row, size_t vec_size,
+                   pasta::Ciphertext &destination)
+{
+    const size_t w = ctx.ct_words();
+    pasta::detail::DevBuf a(w * 8), b(w * 8), o(w * 8);
+    hhe_ctx *h = ctx.handle();
+    pasta::detail::check(hhe_copy_h2d(h, a.p, vi.words.data(), w * 8));
+    pasta::detail::check(hhe_copy_h2d(h, b.p, w_row.words.data(), w * 8));
+    pasta::detail::check(hhe_fc_row(h, a.u64(), b.u64(), 1, vec_size, o.u64(), 1));
+    pasta::detail::check(hhe_ctx_sync(h));
+    destination.words.resize(w);
+    destination.size = 2;
+    pasta::detail::check(hhe_copy_d2h(h, destination.words.data(), o.p, w * 8));
+}
+}  // namespace sealhelper

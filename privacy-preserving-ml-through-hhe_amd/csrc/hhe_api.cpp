@@ -95,7 +95,7 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
 {
     const int L = c->L, K = c->K;
     NttArgs a = ntt_args(c, d, c->ws_T, B * L * K, 0, K);
-    a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = d_stride; a.load_op = LOAD_DIGIT;
+    a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = d_stride; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
     k_ntt(a, false, c->stream);
     KsMacArgs m;
     memset(&m, 0, sizeof(m));
@@ -327,14 +327,14 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
         const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
         {   // digits: T[I][J] = NTT_J(d[I] mod q_J); diagonal digits feed the plain product
             NttArgs a = ntt_args(c, c->ws_d, c->ws_T, B * L * K, 0, K);
-            a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT;
-            a.store_op = STORE_DIGIT_DIAG; a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.acc = accp1;
+            a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
             k_ntt(a, false, c->stream);
         }
         {
             KsMacArgs m;
             memset(&m, 0, sizeof(m));
             m.T = c->ws_T; m.key = key; m.S = c->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
+            m.acc = accp1; m.mul_ptrs = d_pdiag_ptrs; m.mul_shift = shift;
             k_ks_mac(m, c->stream);
         }
         {   // r_k = INTT(S_k[special]) + floor(q_sp/2)

@@ -63,6 +63,7 @@ struct NttArgs {
     int src_item_polys;   // polys of one batch item in p-space (0 => whole batch is one item)
     size_t src_item_stride;  // words between items in src
     int load_op, store_op;
+    int digit_reduce;  // DIGIT: 1 if some q_I >= 4*q_J (else the lazy butterflies absorb the unreduced residue)
     u64 t;          // LIFT: plain modulus
     // STORE_MUL / STORE_MAC multiplier (NTT form): (mul_ptrs ? mul_ptrs[p / mul_item_polys] : mul)
     //   + mul_shift + (p % mul_cycle) * N
@@ -105,6 +106,10 @@ struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
     u64 *S;          // [B][2][K][N]
     const ModDev *mods;
     int logn, B, L, K;
+    // optional (fused matmul): acc[b][J][n] += T[b][J][J][n] * mul_ptrs[b][mul_shift + J*N + n] for J < L
+    u64 *acc;
+    const u64 *const *mul_ptrs;
+    size_t mul_shift;
 };
 
 struct PermArgs {  // NTT-domain Galois permutation: out[p][x] (op)= in[p][pi_elt(x)] (* mul)

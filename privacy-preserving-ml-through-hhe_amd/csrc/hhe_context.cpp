@@ -3,6 +3,7 @@
 // NTTTables (seal/util/ntt.h:69-183), BatchEncoder index map (seal/batchencoder.h),
 // RNSTool's BEHZ base (seal/util/rns.h:324-399), the BFV scaling-variant constants
 // (seal/context.h:350-401).  See SURVEY.md Appendix A for the restated arithmetic.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -271,6 +272,12 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     c->ksc.half = kf.half;
     for (int j = 0; j < L; ++j) { c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j]; }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
+    {   // a digit d_I < q_I may enter NTT_J unreduced when q_I < 4 q_J (butterfly inputs live in [0,4q))
+        u64 qmax = 0, qmin = ~(u64)0;
+        for (int i = 0; i < L; ++i) qmax = std::max(qmax, c->q[i]);
+        for (int i = 0; i < K; ++i) qmin = std::min(qmin, c->q[i]);
+        c->digit_reduce = (qmax / 4 >= qmin) ? 1 : 0;
+    }
     kf.mods = c->d_mods; kf.logn = logn; kf.L = L; kf.K = K;
     ap.mods = c->d_mods; ap.logn = logn; ap.L = L;
     *out = c;

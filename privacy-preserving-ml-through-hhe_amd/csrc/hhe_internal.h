@@ -24,6 +24,7 @@ struct hhe_ctx {
     int nmod = 0;                  // K + (L+1) + 1
     int mod_t = 0;                 // index of the plain modulus
     rt_stream stream = nullptr;
+    int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
     int matmul_mode = 1;           // 1: fused 20-transform pipeline (default), 0: op-by-op schedule
     KsConsts ksc{};
 

@@ -83,7 +83,7 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
         else { x = e & (g.M - 1); lane = e >> a.logm; }
         u64 v = src[ntt_gidx<STRIDED>(g, x, lane)];
         if (FIRST) {
-            if (a.load_op == LOAD_DIGIT) v = reduce64(v, m);
+            if (a.load_op == LOAD_DIGIT) { if (a.digit_reduce) v = reduce64(v, m); }
             else if (a.load_op == LOAD_LIFT) v = (v >= ((a.t + 1) >> 1)) ? v + (m.q - a.t) : v;
             else if (a.load_op == LOAD_RNEG) v = submod(reduce64(v, m), a.ks.half_mod[g.poly % a.L], m.q);
         }
@@ -298,6 +298,10 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
     u64 r0 = 0, r1 = 0;
     for (int I = 0; I < a.L; I++) {
         const u64 t = a.T[((b * a.L + I) * a.K + J) * n + i];
+        if (a.acc && I == J) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product
+            u64 *ap = a.acc + (b * a.L + J) * n + i;
+            *ap = addmod(*ap, mulmod(t, a.mul_ptrs[b][a.mul_shift + (size_t)J * n + i], m), m.q);
+        }
         acc_mac(s0, t, a.key[(((size_t)I * 2 + 0) * a.K + J) * n + i]);
         acc_mac(s1, t, a.key[(((size_t)I * 2 + 1) * a.K + J) * n + i]);
         if ((I & 3) == 3) {  // q < 2^61: four products stay below 2^124

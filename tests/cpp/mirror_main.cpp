@@ -1,0 +1,58 @@
+// mirror_main.cpp -- drives include/pasta_seal_gfx950.hpp the way CSP.cpp:238-251 drives the reference
+// classes: build PASTA_SEAL from context + keys, call decomposition on one record, flatten the blocks.
+// Input/output are raw uint64 blobs written/read by tests/test_cpp_mirror.py.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "pasta_seal_gfx950.hpp"
+
+static std::vector<uint64_t> read_words(FILE *f, size_t n)
+{
+    std::vector<uint64_t> v(n);
+    if (fread(v.data(), 8, n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+    return v;
+}
+int main(int argc, char **argv)
+{
+    if (argc < 3) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    auto hdr = read_words(f, 6);  // logn, K, t, n_galois, n_words, do_flatten
+    const int logn = (int)hdr[0], K = (int)hdr[1];
+    const size_t n = (size_t)1 << logn, L = K - 1, ksk = L * 2 * K * n, ctw = 2 * L * n;
+    auto q = read_words(f, K);
+    pasta::RelinKeys rk{read_words(f, ksk)};
+    pasta::GaloisKeys gk;
+    for (uint64_t i = 0; i < hdr[3]; i++) {
+        uint32_t elt = (uint32_t)read_words(f, 1)[0];
+        gk.keys[elt] = read_words(f, ksk);
+    }
+    pasta::Ciphertext enc_key{read_words(f, ctw), 2};
+    auto record = read_words(f, hdr[4]);
+    fclose(f);
+    try {
+        auto ctx = std::make_shared<pasta::HheContext>(logn, q, hdr[2], 0);
+        pasta::PASTA_SEAL HHE(ctx, pasta::PublicKey{}, pasta::SecretKey{}, rk, gk);
+        HHE.add_gk_indices();
+        std::vector<pasta::Ciphertext> blocks = HHE.decomposition(record, {enc_key}, true);
+        FILE *o = fopen(argv[2], "wb");
+        uint64_t nb = blocks.size();
+        fwrite(&nb, 8, 1, o);
+        for (auto &b : blocks) fwrite(b.words.data(), 8, b.words.size(), o);
+        if (hdr[5]) {
+            pasta::Ciphertext flat;
+            HHE.flatten(blocks, flat);
+            fwrite(flat.words.data(), 8, flat.words.size(), o);
+        }
+        fclose(o);
+        // error behaviour: a context without Galois keys must throw like SEAL does
+        pasta::PASTA_SEAL bare(std::make_shared<pasta::HheContext>(logn, q, hdr[2], 0), {}, {}, rk, {});
+        try { bare.decomposition(record, {enc_key}); printf("NO THROW\n"); return 3; }
+        catch (const std::invalid_argument &e) { printf("throws: %s\n", e.what()); }
+    } catch (const std::exception &e) {
+        fprintf(stderr, "exception: %s\n", e.what());
+        return 1;
+    }
+    printf("mirror ok (%s)\n", hhe_backend());
+    return 0;
+}

@@ -1,0 +1,65 @@
+"""The C++ host-side mirror of pasta::PASTA_SEAL (include/pasta_seal_gfx950.hpp) driven like CSP.cpp:238-278:
+decomposition of a multi-block record + flatten, compared with the oracle.  Runs on the CPU against the
+tests-only emulator library and, marked gpu, against libhhe_gfx950.so."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import Setup
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(orc, tmp_path, libdir, libname, extra_env=None):
+    S = Setup(orc, 10, [50] * 9, extra_steps=(-128, -256))
+    O = S.O
+    pt = np.array([(7 * i + 3) % 256 for i in range(300)], dtype=np.uint64)
+    record = orc.pasta_encrypt(S.t, S.key, pt)
+    blob = tmp_path / "in.bin"
+    with open(blob, "wb") as f:
+        np.array([S.logn, O.K, S.t, len(S.gk.elts), len(record), 1], dtype=np.uint64).tofile(f)
+        np.array(S.q, dtype=np.uint64).tofile(f)
+        S.rk.tofile(f)
+        for e, k in zip(S.gk.elts, S.gk.keys):
+            np.array([int(e)], dtype=np.uint64).tofile(f)
+            k.tofile(f)
+        S.enc_key.tofile(f)
+        record.tofile(f)
+    exe = tmp_path / "mirror"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "mirror_main.cpp"), "-L" + libdir, "-l" + libname,
+                           "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = tmp_path / "out.bin"
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    r = subprocess.run([str(exe), str(blob), str(out)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "throws: Galois key not present" in r.stdout
+    words = np.fromfile(out, dtype=np.uint64)
+    nb = int(words[0])
+    assert nb == 3
+    cts = words[1:].reshape(nb + 1, *O.ct_shape)
+    cw, ncw = S.sym_blocks(orc, pt)
+    refs = [O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b) for b in range(nb)]
+    for b in range(nb):
+        assert (cts[b] == refs[b]).all()
+    flat = O.flatten(np.stack(refs), S.gk)
+    assert (cts[nb] == flat).all()
+    # mask-free flatten decrypts to the record (SEAL_Cipher.cpp:170-181 semantics): first 300 slots
+    dec = O.decode(O.decrypt(S.sk, cts[nb]))
+    assert (dec[:256] == pt[:256]).all()
+    return r.stdout
+
+
+def test_cpp_mirror_on_emulator(orc, emu_lib, tmp_path):
+    out = _run(orc, tmp_path, os.path.join(ROOT, "tests", "emu"), "hhe_emu")
+    assert "emulator" in out
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_on_gfx950(orc, tmp_path):
+    libdir = os.path.join(ROOT, "privacy-preserving-ml-through-hhe_amd", "csrc")
+    out = _run(orc, tmp_path, libdir, "hhe_gfx950")
+    assert "hip-gfx950" in out

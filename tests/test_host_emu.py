@@ -119,3 +119,11 @@ def test_fused_matmul_equals_op_by_op_schedule(orc, api, emu_lib, mem, small, mo
         outs.append(mem.to_host(out))
     assert (outs[0] == outs[1]).all()
     assert (outs[0][0] == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[0], 5)).all()
+
+
+def test_mixed_prime_sizes_force_digit_reduction(orc, api, emu_lib, mem):
+    # 50-bit data primes vs 36-bit ones: q_I >= 4 q_J, so key-switch digits must be reduced before NTT_J
+    S = Setup(orc, 10, [36, 36, 50, 50, 50])
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    pc.check_ops(X, S, mem, B=2, seed=11)
