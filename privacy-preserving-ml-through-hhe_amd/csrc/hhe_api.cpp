@@ -16,11 +16,8 @@ int dev_fail(const char *where) { return fail(HHE_ERR_DEVICE, std::string(where)
 int need(hhe_ctx *c, size_t B)
 {
     if (!c || B == 0) return fail(HHE_ERR_INVALID, "null context or empty batch");
-    if (B > c->cap) {
-        int rc = hhe_ctx_reserve(c, B);
-        if (rc) return rc;
-    }
-    return HHE_OK;
+    c->w = &c->lanes[0];
+    return lane_reserve(c, c->lanes[0], B);
 }
 
 NttArgs ntt_args(const hhe_ctx *c, const u64 *src, u64 *dst, size_t count, int mod_base, int mod_cycle)
@@ -37,7 +34,7 @@ void op_ntt(hhe_ctx *c, u64 *polys, size_t count, int mod_base, int mod_cycle, b
 {
     NttArgs a = ntt_args(c, polys, polys, count, mod_base, mod_cycle);
     a.store_op = store_op;
-    k_ntt(a, inverse, c->stream);
+    k_ntt(a, inverse, c->w->stream);
 }
 void op_elt(hhe_ctx *c, int op, const u64 *x, const u64 *y, u64 *out, size_t count, int mod_base, int mod_cycle, int b_cycle = 0)
 {
@@ -45,7 +42,7 @@ void op_elt(hhe_ctx *c, int op, const u64 *x, const u64 *y, u64 *out, size_t cou
     memset(&a, 0, sizeof(a));
     a.a = x; a.b = y; a.out = out; a.mods = c->d_mods; a.logn = c->logn; a.count = (int)count;
     a.mod_base = mod_base; a.mod_cycle = mod_cycle; a.b_cycle = b_cycle;
-    k_elt(a, op, c->stream);
+    k_elt(a, op, c->w->stream);
 }
 // ct (+) ct over [B][size][L][N]
 void op_add(hhe_ctx *c, const u64 *x, const u64 *y, u64 *out, size_t B, int size) { op_elt(c, ELT_ADD, x, y, out, B * size * c->L, 0, c->L); }
@@ -56,18 +53,18 @@ void op_add_plain(hhe_ctx *c, const u64 *ct, const u64 *plain, const u64 *const 
     AddPlainArgs a = c->apl;
     a.ct = ct; a.plain = plain; a.plain_ptrs = plain_ptrs; a.plain_shift = shift; a.out = out; a.B = (int)B;
     a.plain_bcast = bcast; a.subtract = subtract; a.negate_ct = negate;
-    k_add_plain(a, c->stream);
+    k_add_plain(a, c->w->stream);
 }
 
 // BatchEncoder::encode: vals [B][stride] (first `count` used) -> plain [B][N]
 void op_encode(hhe_ctx *c, const u64 *vals, size_t B, int stride, int count, int second_off, u64 *plain)
 {
-    rt_memset(plain, 0, B * c->n * 8, c->stream);
+    rt_memset(plain, 0, B * c->n * 8, c->w->stream);
     EncodeArgs e;
     memset(&e, 0, sizeof(e));
     e.vals = vals; e.out = plain; e.slot_map = c->d_slot_map; e.logn = c->logn; e.B = (int)B;
     e.stride = stride; e.count = count; e.second_off = second_off; e.t = c->t;
-    k_encode_scatter(e, c->stream);
+    k_encode_scatter(e, c->w->stream);
     op_ntt(c, plain, B, c->mod_t, 1, true);
 }
 
@@ -76,7 +73,7 @@ void op_lift_ntt(hhe_ctx *c, const u64 *plain, size_t P, u64 *out)
 {
     NttArgs a = ntt_args(c, plain, out, P * c->L, 0, c->L);
     a.src_div = c->L; a.load_op = LOAD_LIFT;
-    k_ntt(a, false, c->stream);
+    k_ntt(a, false, c->w->stream);
 }
 
 // out = INTT(NTT(ct) * D) with D an NTT-form lifted plaintext: shared [L][N] (ptrs null) or per item
@@ -84,7 +81,7 @@ void op_multiply_plain_ntt(hhe_ctx *c, const u64 *ct, const u64 *D, const u64 *c
 {
     NttArgs a = ntt_args(c, ct, out, B * 2 * c->L, 0, c->L);
     a.store_op = STORE_MUL; a.mul = D; a.mul_ptrs = D_ptrs; a.mul_shift = shift; a.mul_cycle = c->L; a.mul_item_polys = 2 * c->L;
-    k_ntt(a, false, c->stream);
+    k_ntt(a, false, c->w->stream);
     op_ntt(c, out, B * 2 * c->L, 0, c->L, true);
 }
 
@@ -94,17 +91,17 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
                    int base_mask, u64 *out, size_t B)
 {
     const int L = c->L, K = c->K;
-    NttArgs a = ntt_args(c, d, c->ws_T, B * L * K, 0, K);
+    NttArgs a = ntt_args(c, d, c->w->ws_T, B * L * K, 0, K);
     a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = d_stride; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
-    k_ntt(a, false, c->stream);
+    k_ntt(a, false, c->w->stream);
     KsMacArgs m;
     memset(&m, 0, sizeof(m));
-    m.T = c->ws_T; m.key = key; m.S = c->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
-    k_ks_mac(m, c->stream);
-    op_ntt(c, c->ws_S, B * 2 * K, 0, K, true);
+    m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
+    k_ks_mac(m, c->w->stream);
+    op_ntt(c, c->w->ws_S, B * 2 * K, 0, K, true);
     KsFinishArgs f = c->ksf;
-    f.S = c->ws_S; f.base = base; f.base_item_stride = base_stride; f.base_mask = base ? base_mask : 0; f.out = out; f.B = (int)B;
-    k_ks_finish(f, c->stream);
+    f.S = c->w->ws_S; f.base = base; f.base_item_stride = base_stride; f.base_mask = base ? base_mask : 0; f.out = out; f.B = (int)B;
+    k_ks_finish(f, c->w->stream);
 }
 
 int op_apply_galois(hhe_ctx *c, const u64 *ct, u32 elt, u64 *out, size_t B)
@@ -119,15 +116,15 @@ int op_apply_galois(hhe_ctx *c, const u64 *ct, u32 elt, u64 *out, size_t B)
     g.einv = (u32)nt_invmod(elt, 2 * n);
     const u64 *src = ct;
     if (ct == out) {  // gather cannot run in place
-        rt_d2d(c->ws_ct[3], ct, B * c->ct_words() * 8, c->stream);
-        src = c->ws_ct[3];
+        rt_d2d(c->w->ws_ct[3], ct, B * c->ct_words() * 8, c->w->stream);
+        src = c->w->ws_ct[3];
     }
     // c0' = galois(c0) -> out poly 0 ; d = galois(c1) -> ws_d
     g.in = src; g.in_item_stride = 2 * L * n; g.out = out; g.out_item_stride = 2 * L * n;
-    k_galois(g, c->stream);
-    g.in = src + L * n; g.out = c->ws_d; g.out_item_stride = L * n;
-    k_galois(g, c->stream);
-    op_switch_key(c, c->ws_d, L * n, it->second, out, 2 * L * n, 1, out, B);
+    k_galois(g, c->w->stream);
+    g.in = src + L * n; g.out = c->w->ws_d; g.out_item_stride = L * n;
+    k_galois(g, c->w->stream);
+    op_switch_key(c, c->w->ws_d, L * n, it->second, out, 2 * L * n, 1, out, B);
     return HHE_OK;
 }
 
@@ -135,7 +132,7 @@ int op_apply_galois(hhe_ctx *c, const u64 *ct, u32 elt, u64 *out, size_t B)
 int op_rotate_rows(hhe_ctx *c, const u64 *ct, int step, u64 *out, size_t B)
 {
     if (step == 0) {
-        if (ct != out) rt_d2d(out, ct, B * c->ct_words() * 8, c->stream);
+        if (ct != out) rt_d2d(out, ct, B * c->ct_words() * 8, c->w->stream);
         return HHE_OK;
     }
     const u32 elt = galois_elt_from_step(c, step);
@@ -150,7 +147,7 @@ int op_rotate_rows(hhe_ctx *c, const u64 *ct, int step, u64 *out, size_t B)
         if (rc) return rc;
         cur = out;
     }
-    if (cur == ct && ct != out) rt_d2d(out, ct, B * c->ct_words() * 8, c->stream);
+    if (cur == ct && ct != out) rt_d2d(out, ct, B * c->ct_words() * 8, c->w->stream);
     return HHE_OK;
 }
 
@@ -162,28 +159,28 @@ void op_multiply(hhe_ctx *c, const u64 *x, const u64 *y, u64 *out3, size_t B)
         BehzExtendArgs e;
         memset(&e, 0, sizeof(e));
         e.x = in; e.xb = ob; e.mods = c->d_mods; e.bz = c->d_behz; e.logn = c->logn; e.P = (int)(B * 2); e.L = L; e.K = K;
-        k_behz_extend(e, c->stream);
+        k_behz_extend(e, c->w->stream);
         op_ntt(c, ob, B * 2 * (L + 1), K, L + 1, false);
         NttArgs a = ntt_args(c, in, oq, B * 2 * L, 0, L);
-        k_ntt(a, false, c->stream);
+        k_ntt(a, false, c->w->stream);
     };
-    extend(x, c->bz_aq, c->bz_ab);
-    const u64 *bq = c->bz_aq, *bb = c->bz_ab;
-    if (y != x) { extend(y, c->bz_bq, c->bz_bb); bq = c->bz_bq; bb = c->bz_bb; }
+    extend(x, c->w->bz_aq, c->w->bz_ab);
+    const u64 *bq = c->w->bz_aq, *bb = c->w->bz_ab;
+    if (y != x) { extend(y, c->w->bz_bq, c->w->bz_bb); bq = c->w->bz_bq; bb = c->w->bz_bb; }
     TensorArgs t;
     memset(&t, 0, sizeof(t));
     t.mods = c->d_mods; t.logn = c->logn; t.B = (int)B;
-    t.a = c->bz_aq; t.b = bq; t.d = c->bz_dq; t.limbs = L; t.mod_base = 0;
-    k_tensor(t, c->stream);
-    t.a = c->bz_ab; t.b = bb; t.d = c->bz_db; t.limbs = L + 1; t.mod_base = K;
-    k_tensor(t, c->stream);
-    op_ntt(c, c->bz_dq, B * 3 * L, 0, L, true, STORE_SCALE_T);
-    op_ntt(c, c->bz_db, B * 3 * (L + 1), K, L + 1, true, STORE_SCALE_T);
+    t.a = c->w->bz_aq; t.b = bq; t.d = c->w->bz_dq; t.limbs = L; t.mod_base = 0;
+    k_tensor(t, c->w->stream);
+    t.a = c->w->bz_ab; t.b = bb; t.d = c->w->bz_db; t.limbs = L + 1; t.mod_base = K;
+    k_tensor(t, c->w->stream);
+    op_ntt(c, c->w->bz_dq, B * 3 * L, 0, L, true, STORE_SCALE_T);
+    op_ntt(c, c->w->bz_db, B * 3 * (L + 1), K, L + 1, true, STORE_SCALE_T);
     BehzFloorArgs f;
     memset(&f, 0, sizeof(f));
-    f.dq = c->bz_dq; f.db = c->bz_db; f.out = out3; f.mods = c->d_mods; f.bz = c->d_behz; f.logn = c->logn;
+    f.dq = c->w->bz_dq; f.db = c->w->bz_db; f.out = out3; f.mods = c->d_mods; f.bz = c->d_behz; f.logn = c->logn;
     f.P = (int)(B * 3); f.L = L; f.K = K;
-    k_behz_floor(f, c->stream);
+    k_behz_floor(f, c->w->stream);
 }
 
 int op_relinearize(hhe_ctx *c, const u64 *a3, u64 *out, size_t B)
@@ -205,10 +202,10 @@ int ensure_feistel_mask(hhe_ctx *c)
     u64 *dv = (u64 *)rt_malloc(vals.size() * 8), *pl = (u64 *)rt_malloc(n * 8);
     c->d_feistel_mask = (u64 *)rt_malloc((size_t)c->L * n * 8);
     if (!dv || !pl || !c->d_feistel_mask) return dev_fail("feistel mask alloc");
-    rt_h2d(dv, vals.data(), vals.size() * 8, c->stream);
+    rt_h2d(dv, vals.data(), vals.size() * 8, c->w->stream);
     op_encode(c, dv, 1, 2 * PASTA_T, PASTA_T, (int)half, pl);
     op_lift_ntt(c, pl, 1, c->d_feistel_mask);
-    if (rt_sync(c->stream)) return dev_fail("feistel mask");
+    if (rt_sync(c->w->stream)) return dev_fail("feistel mask");
     rt_free(dv); rt_free(pl);
     return HHE_OK;
 }
@@ -228,14 +225,14 @@ int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
     bt.diag = (u64 *)rt_malloc(ndiag * L * n * 8);
     bt.rc = (u64 *)rt_malloc((size_t)(PASTA_R + 1) * n * 8);
     if (!d_mats || !d_rcs || !slots || !bt.diag || !bt.rc) return dev_fail("block table alloc");
-    rt_h2d(d_mats, mats.data(), mats.size() * 8, c->stream);
-    rt_h2d(d_rcs, rcs.data(), rcs.size() * 8, c->stream);
+    rt_h2d(d_mats, mats.data(), mats.size() * 8, c->w->stream);
+    rt_h2d(d_rcs, rcs.data(), rcs.size() * 8, c->w->stream);
     // 128 diagonals per affine layer -> slot image -> INTT mod t (= batch encode) -> lift + NTT per limb
-    rt_memset(slots, 0, ndiag * n * 8, c->stream);
+    rt_memset(slots, 0, ndiag * n * 8, c->w->stream);
     DiagArgs d;
     memset(&d, 0, sizeof(d));
     d.mats = d_mats; d.out = slots; d.slot_map = c->d_slot_map; d.logn = c->logn;
-    k_diag(d, c->stream);
+    k_diag(d, c->w->stream);
     op_ntt(c, slots, ndiag, c->mod_t, 1, true);
     op_lift_ntt(c, slots, ndiag, bt.diag);
     // round constants: rc1 -> slots [0,128), rc2 -> slots [N/2, N/2+128) (pasta_3_plain.cpp:286-295)
@@ -248,9 +245,9 @@ int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
         memset(&p, 0, sizeof(p));
         p.in = bt.diag; p.out = bt.pdiag; p.mods = c->d_mods; p.logn = c->logn; p.count = (int)(ndiag * L); p.L = L;
         p.out_item_stride = (size_t)L * n; p.elt = galois_elt_from_step(c, -1);
-        k_perm(p, c->stream);
+        k_perm(p, c->w->stream);
     }
-    if (rt_sync(c->stream)) return dev_fail("block tables");
+    if (rt_sync(c->w->stream)) return dev_fail("block tables");
     rt_free(d_mats); rt_free(d_rcs); rt_free(slots);
     auto ins = c->blocks.emplace(block, bt);
     *out = &ins.first->second;
@@ -264,13 +261,13 @@ int matmul_diagonal(hhe_ctx *c, int layer, const u64 *const *d_diag_ptrs, size_t
 {
     const int L = c->L;
     const size_t n = c->n;
-    u64 *state = c->ws_ct[0], *acc = c->ws_ct[1], *scratch = c->ws_ct[2];
+    u64 *state = c->w->ws_ct[0], *acc = c->w->ws_ct[1], *scratch = c->w->ws_ct[2];
     if (n / 2 != PASTA_T) {
         int rc = op_rotate_rows(c, state, PASTA_T, scratch, B);
         if (rc) return rc;
         op_add(c, state, scratch, state, B, 2);
     }
-    rt_memset(acc, 0, B * c->ct_words() * 8, c->stream);
+    rt_memset(acc, 0, B * c->ct_words() * 8, c->w->stream);
     for (int i = 0; i < PASTA_T; ++i) {
         if (i) {
             int rc = op_rotate_rows(c, state, -1, state, B);
@@ -279,10 +276,10 @@ int matmul_diagonal(hhe_ctx *c, int layer, const u64 *const *d_diag_ptrs, size_t
         NttArgs a = ntt_args(c, state, scratch, B * 2 * L, 0, L);
         a.store_op = STORE_MAC; a.mul_ptrs = d_diag_ptrs; a.mul_shift = ((size_t)layer * PASTA_T + i) * L * n;
         a.mul_cycle = L; a.mul_item_polys = 2 * L; a.acc = acc;
-        k_ntt(a, false, c->stream);
+        k_ntt(a, false, c->w->stream);
     }
     op_ntt(c, acc, B * 2 * L, 0, L, true);
-    rt_d2d(state, acc, B * c->ct_words() * 8, c->stream);
+    rt_d2d(state, acc, B * c->ct_words() * 8, c->w->stream);
     return HHE_OK;
 }
 
@@ -297,82 +294,82 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
 {
     const int L = c->L, K = c->K;
     const size_t n = c->n, ln = (size_t)L * n, bln = B * ln;
-    u64 *state = c->ws_ct[0];
+    u64 *state = c->w->ws_ct[0];
     if (n / 2 != PASTA_T) {
-        int rc = op_rotate_rows(c, state, PASTA_T, c->ws_ct[2], B);
+        int rc = op_rotate_rows(c, state, PASTA_T, c->w->ws_ct[2], B);
         if (rc) return rc;
-        op_add(c, state, c->ws_ct[2], state, B, 2);
+        op_add(c, state, c->w->ws_ct[2], state, B, 2);
     }
     const u32 g = galois_elt_from_step(c, -1);
     auto it = c->d_gk.find(g);
     if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     const u64 *key = it->second;
     const u32 ginv = (u32)nt_invmod(g, 2 * n);
-    u64 *accp0 = c->ws_ct[1], *accp1 = c->ws_ct[1] + bln;
-    u64 *c0n[2] = {c->ws_ct[2], c->ws_ct[2] + bln};
-    u64 *scr = c->ws_ct[3], *r = c->ws_ct[3] + bln;
-    rt_memset(c->ws_ct[1], 0, 2 * bln * 8, c->stream);
+    u64 *accp0 = c->w->ws_ct[1], *accp1 = c->w->ws_ct[1] + bln;
+    u64 *c0n[2] = {c->w->ws_ct[2], c->w->ws_ct[2] + bln};
+    u64 *scr = c->w->ws_ct[3], *r = c->w->ws_ct[3] + bln;
+    rt_memset(c->w->ws_ct[1], 0, 2 * bln * 8, c->w->stream);
     {   // c0 -> NTT form ; d = galois(c1)
         NttArgs a = ntt_args(c, state, c0n[0], B * L, 0, L);
         a.src_item_polys = L; a.src_item_stride = 2 * ln;
-        k_ntt(a, false, c->stream);
+        k_ntt(a, false, c->w->stream);
         GaloisArgs ga;
         memset(&ga, 0, sizeof(ga));
         ga.mods = c->d_mods; ga.logn = c->logn; ga.count = (int)(B * L); ga.L = L; ga.einv = ginv;
-        ga.in = state + ln; ga.in_item_stride = 2 * ln; ga.out = c->ws_d; ga.out_item_stride = ln;
-        k_galois(ga, c->stream);
+        ga.in = state + ln; ga.in_item_stride = 2 * ln; ga.out = c->w->ws_d; ga.out_item_stride = ln;
+        k_galois(ga, c->w->stream);
     }
     int cur = 0;
     for (int i = 0; i < PASTA_T - 1; ++i) {
         const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
         {   // digits: T[I][J] = NTT_J(d[I] mod q_J); diagonal digits feed the plain product
-            NttArgs a = ntt_args(c, c->ws_d, c->ws_T, B * L * K, 0, K);
+            NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
             a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
-            k_ntt(a, false, c->stream);
+            k_ntt(a, false, c->w->stream);
         }
         {
             KsMacArgs m;
             memset(&m, 0, sizeof(m));
-            m.T = c->ws_T; m.key = key; m.S = c->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
+            m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
             m.acc = accp1; m.mul_ptrs = d_pdiag_ptrs; m.mul_shift = shift;
-            k_ks_mac(m, c->stream);
+            k_ks_mac(m, c->w->stream);
         }
         {   // r_k = INTT(S_k[special]) + floor(q_sp/2)
-            NttArgs a = ntt_args(c, c->ws_S + (size_t)(K - 1) * n, r, B * 2, K - 1, 1);
+            NttArgs a = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, r, B * 2, K - 1, 1);
             a.src_item_polys = 1; a.src_item_stride = (size_t)K * n; a.store_op = STORE_RSP;
-            k_ntt(a, true, c->stream);
+            k_ntt(a, true, c->w->stream);
         }
         {   // c1 of the next state, coefficient form, already passed through the Galois map for the next digits
-            NttArgs a = ntt_args(c, c->ws_S + (size_t)K * n, scr, B * L, 0, L);
+            NttArgs a = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
             a.src_item_polys = L; a.src_item_stride = (size_t)2 * K * n; a.store_op = STORE_KS1;
-            a.aux_r = r; a.aux_out = c->ws_d; a.gal_elt = g;
-            k_ntt(a, true, c->stream);
+            a.aux_r = r; a.aux_out = c->w->ws_d; a.gal_elt = g;
+            k_ntt(a, true, c->w->stream);
         }
         {   // c0 of the next state in NTT form + permuted-frame product of the current c0
             NttArgs a = ntt_args(c, r, scr, B * L, 0, L);
             a.src_item_polys = L; a.src_item_stride = 2 * n; a.src_div = L; a.load_op = LOAD_RNEG;
-            a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.aux_r = c->ws_S; a.acc = accp0;
+            a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.aux_r = c->w->ws_S; a.acc = accp0;
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g;
-            k_ntt(a, false, c->stream);
+            k_ntt(a, false, c->w->stream);
         }
         cur ^= 1;
     }
     const size_t shift = ((size_t)layer * PASTA_T + (PASTA_T - 1)) * ln;
     {   // last state: products only (a "virtual" rotation keeps the frame uniform)
-        NttArgs a = ntt_args(c, c->ws_d, scr, B * L, 0, L);
+        NttArgs a = ntt_args(c, c->w->ws_d, scr, B * L, 0, L);
         a.store_op = STORE_MAC; a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.mul_cycle = L; a.mul_item_polys = L; a.acc = accp1;
-        k_ntt(a, false, c->stream);
+        k_ntt(a, false, c->w->stream);
         PermArgs p;
         memset(&p, 0, sizeof(p));
         p.in = c0n[cur]; p.out = accp0; p.mods = c->d_mods; p.logn = c->logn; p.count = (int)(B * L); p.L = L;
         p.out_item_stride = ln; p.elt = g; p.mac = 1; p.mul_ptrs = d_pdiag_ptrs; p.mul_shift = shift;
-        k_perm(p, c->stream);
+        k_perm(p, c->w->stream);
         // back to the unrotated frame, then to coefficient form
         p.mac = 0; p.mul_ptrs = nullptr; p.elt = ginv; p.out_item_stride = 2 * ln;
         p.in = accp0; p.out = state;
-        k_perm(p, c->stream);
+        k_perm(p, c->w->stream);
         p.in = accp1; p.out = state + ln;
-        k_perm(p, c->stream);
+        k_perm(p, c->w->stream);
     }
     op_ntt(c, state, B * 2 * L, 0, L, true);
     return HHE_OK;
@@ -384,6 +381,14 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
 extern "C" int hhe_ntt(hhe_ctx *c, uint64_t *polys, size_t count, int mod_base, int mod_cycle, int inverse)
 {
     if (!c || !polys || mod_cycle < 1 || mod_base < 0 || mod_base + mod_cycle > c->nmod) return fail(HHE_ERR_INVALID, "hhe_ntt: bad arguments");
+    if (const char *probe = getenv("HHE_NTT_PROBE")) {  // timing probes for tools/ntt_micro.py (results are garbage)
+        NttArgs a = ntt_args(c, polys, polys, count, mod_base, mod_cycle);
+        const int p = atoi(probe);
+        if (p & 1) a.load_op = 99;
+        if (p & 2) a.store_op = 99;
+        k_ntt(a, inverse != 0, c->w->stream);
+        return HHE_OK;
+    }
     op_ntt(c, polys, count, mod_base, mod_cycle, inverse != 0);
     return HHE_OK;
 }
@@ -417,7 +422,7 @@ extern "C" int hhe_multiply_plain(hhe_ctx *c, const uint64_t *ct, const uint64_t
     int rc = need(c, B);
     if (rc) return rc;
     const size_t P = bcast ? 1 : B;
-    u64 *D = c->ws_ct3;  // [P][L][N] fits in [B][3][L][N]
+    u64 *D = c->w->ws_ct3;  // [P][L][N] fits in [B][3][L][N]
     op_lift_ntt(c, plain, P, D);
     if (bcast) op_multiply_plain_ntt(c, ct, D, nullptr, 0, out, B);
     else {
@@ -428,11 +433,11 @@ extern "C" int hhe_multiply_plain(hhe_ctx *c, const uint64_t *ct, const uint64_t
         for (size_t b = 0; b < B; ++b) ptrs[b] = D + b * c->L * c->n;
         const u64 **dp = (const u64 **)rt_malloc(B * sizeof(u64 *));
         if (!dp) return dev_fail("hhe_multiply_plain");
-        rt_h2d(dp, ptrs.data(), B * sizeof(u64 *), c->stream);
+        rt_h2d(dp, ptrs.data(), B * sizeof(u64 *), c->w->stream);
         a.mul_ptrs = dp; a.mul_cycle = c->L; a.mul_item_polys = 2 * c->L;
-        k_ntt(a, false, c->stream);
+        k_ntt(a, false, c->w->stream);
         op_ntt(c, out, B * 2 * c->L, 0, c->L, true);
-        rt_sync(c->stream);
+        rt_sync(c->w->stream);
         rt_free(dp);
     }
     return HHE_OK;
@@ -469,45 +474,22 @@ extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, si
     return op_relinearize(c, a3, out, B);
 }
 
-extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *cw, const uint32_t *ncw,
-                                      const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
+// one chunk of the batch on the current lane (c->w): the schedule of PASTA_SEAL::decomposition (pasta_3_seal.cpp:123-170)
+static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d_diag, const u64 *const *d_rc,
+                             const u64 *cw_padded_host, u64 *out, size_t B)
 {
-    if (!c || !enc_key || !cw || !ncw || !block_index || !out) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: null argument");
-    if (use_bsgs) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: babystep-giantstep variant not built yet");
-    const size_t n = c->n, half = n / 2;
+    const size_t n = c->n;
     const int L = c->L;
-    // pasta_3_seal.cpp:376-377
-    if ((size_t)PASTA_T * 2 != n && (size_t)PASTA_T * 4 > n) return fail(HHE_ERR_TOO_FEW_SLOTS, "too little slots for matmul implementation!");
-    if (!c->d_rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
-    for (int step : {-1, half != PASTA_T ? PASTA_T : -1, 0})
-        if (!c->d_gk.count(galois_elt_from_step(c, step))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
-    int rc = need(c, B);
-    if (rc) return rc;
-    if ((rc = ensure_feistel_mask(c))) return rc;
-    // per-item public tables
-    std::vector<const u64 *> diag_ptrs(B), rc_ptrs(B);
     const bool fused = c->matmul_mode == 1;
-    std::vector<u64> cwp(B * PASTA_T, 0);
-    for (size_t b = 0; b < B; ++b) {
-        if (ncw[b] > PASTA_T) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: more than 128 words in a block");
-        BlockTables *bt = nullptr;
-        if ((rc = ensure_block(c, block_index[b], &bt))) return rc;
-        diag_ptrs[b] = fused ? bt->pdiag : bt->diag; rc_ptrs[b] = bt->rc;
-        memcpy(&cwp[b * PASTA_T], cw + b * PASTA_T, ncw[b] * 8);
-    }
-    const u64 **d_ptrs = (const u64 **)rt_malloc(2 * B * sizeof(u64 *));
-    if (!d_ptrs) return dev_fail("hhe_pasta3_transcipher");
-    rt_h2d(d_ptrs, diag_ptrs.data(), B * sizeof(u64 *), c->stream);
-    rt_h2d(d_ptrs + B, rc_ptrs.data(), B * sizeof(u64 *), c->stream);
-    rt_h2d(c->ws_vals, cwp.data(), cwp.size() * 8, c->stream);
-
-    u64 *state = c->ws_ct[0], *tmp = c->ws_ct[1], *t3 = c->ws_ct3;
+    int rc = HHE_OK;
+    rt_h2d(c->w->ws_vals, cw_padded_host, B * PASTA_T * 8, c->w->stream);
+    u64 *state = c->w->ws_ct[0], *tmp = c->w->ws_ct[1], *t3 = c->w->ws_ct3;
     // state <- enc_ssk[0] for every item (pasta_3_seal.cpp:126)
     op_elt(c, ELT_BCAST, nullptr, enc_key, state, B * 2 * L, 0, L, 2 * L);
     for (int r = 0; r <= PASTA_R && !rc; ++r) {
-        if ((rc = fused ? matmul_diagonal_fused(c, r, d_ptrs, B) : matmul_diagonal(c, r, d_ptrs, B))) break;
+        if ((rc = fused ? matmul_diagonal_fused(c, r, d_diag, B) : matmul_diagonal(c, r, d_diag, B))) break;
         // add_rc (:205-211)
-        op_add_plain(c, state, nullptr, d_ptrs + B, (size_t)r * n, false, false, false, state, B);
+        op_add_plain(c, state, nullptr, d_rc, (size_t)r * n, false, false, false, state, B);
         // mix (:417-423)
         if ((rc = op_apply_galois(c, state, (u32)(2 * n - 1), tmp, B))) break;
         op_add(c, tmp, state, tmp, B, 2);
@@ -530,10 +512,67 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
     }
     if (!rc) {
         // res = Enc(c_b) - KS : encode, negate, add_plain (:161-169)
-        op_encode(c, c->ws_vals, B, PASTA_T, PASTA_T, -1, c->ws_plain);
-        op_add_plain(c, state, c->ws_plain, nullptr, 0, false, false, true, out, B);
+        op_encode(c, c->w->ws_vals, B, PASTA_T, PASTA_T, -1, c->w->ws_plain);
+        op_add_plain(c, state, c->w->ws_plain, nullptr, 0, false, false, true, out, B);
     }
-    if (rt_sync(c->stream) && !rc) rc = dev_fail("hhe_pasta3_transcipher");
+    return rc;
+}
+
+extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *cw, const uint32_t *ncw,
+                                      const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
+{
+    if (!c || !enc_key || !cw || !ncw || !block_index || !out || B == 0) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: null argument or empty batch");
+    if (use_bsgs) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: babystep-giantstep variant not built yet");
+    const size_t n = c->n, half = n / 2;
+    // pasta_3_seal.cpp:376-377
+    if ((size_t)PASTA_T * 2 != n && (size_t)PASTA_T * 4 > n) return fail(HHE_ERR_TOO_FEW_SLOTS, "too little slots for matmul implementation!");
+    if (!c->d_rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
+    for (int step : {-1, half != PASTA_T ? PASTA_T : -1, 0})
+        if (!c->d_gk.count(galois_elt_from_step(c, step))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    Lane &main = c->lanes[0];
+    c->w = &main;
+    int rc;
+    if ((rc = ensure_feistel_mask(c))) return rc;
+    // per-item public tables
+    std::vector<const u64 *> ptrs(2 * B);
+    std::vector<u64> cwp(B * PASTA_T, 0);
+    for (size_t b = 0; b < B; ++b) {
+        if (ncw[b] > PASTA_T) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: more than 128 words in a block");
+        BlockTables *bt = nullptr;
+        if ((rc = ensure_block(c, block_index[b], &bt))) return rc;
+        ptrs[b] = c->matmul_mode == 1 ? bt->pdiag : bt->diag;
+        ptrs[B + b] = bt->rc;
+        memcpy(&cwp[b * PASTA_T], cw + b * PASTA_T, ncw[b] * 8);
+    }
+    const u64 **d_ptrs = (const u64 **)rt_malloc(2 * B * sizeof(u64 *));
+    if (!d_ptrs) return dev_fail("hhe_pasta3_transcipher");
+    rt_h2d(d_ptrs, ptrs.data(), 2 * B * sizeof(u64 *), main.stream);
+
+    const int ns = c->nstreams;
+    if (ns == 0) {
+        if (!(rc = lane_reserve(c, main, B))) rc = transcipher_chunk(c, enc_key, d_ptrs, d_ptrs + B, cwp.data(), out, B);
+    } else {
+        // independent chunks round-robin over the internal streams: a chunk's working set stays cache resident and
+        // one stream's bandwidth-bound kernels overlap the other's issue-bound transforms
+        const size_t per = std::min(B, c->chunk);
+        for (int s = 1; s <= ns && !rc; ++s) rc = lane_reserve(c, c->lanes[s], per);
+        if (!rc) {
+            rt_event_record(c->ev_fork, main.stream);
+            for (int s = 1; s <= ns; ++s) rt_stream_wait_event(c->lanes[s].stream, c->ev_fork);
+            size_t idx = 0;
+            for (size_t b0 = 0; b0 < B && !rc; b0 += per, ++idx) {
+                const size_t bc = std::min(per, B - b0);
+                c->w = &c->lanes[1 + idx % ns];
+                rc = transcipher_chunk(c, enc_key, d_ptrs + b0, d_ptrs + B + b0, &cwp[b0 * PASTA_T], out + b0 * c->ct_words(), bc);
+            }
+            for (int s = 1; s <= ns; ++s) {
+                rt_event_record(c->lanes[s].ev_done, c->lanes[s].stream);
+                rt_stream_wait_event(main.stream, c->lanes[s].ev_done);
+            }
+        }
+        c->w = &main;
+    }
+    if (rt_sync(main.stream) && !rc) rc = dev_fail("hhe_pasta3_transcipher");
     rt_free(d_ptrs);
     return rc;
 }
@@ -545,12 +584,12 @@ extern "C" int hhe_mask(hhe_ctx *c, const uint64_t *ct, const uint64_t *mask_val
     if (rc) return rc;
     u64 *dv = (u64 *)rt_malloc(count * 8);
     if (!dv) return dev_fail("hhe_mask");
-    rt_h2d(dv, mask_vals, count * 8, c->stream);
-    op_encode(c, dv, 1, (int)count, (int)count, -1, c->ws_plain);
-    u64 *D = c->ws_ct3;
-    op_lift_ntt(c, c->ws_plain, 1, D);
+    rt_h2d(dv, mask_vals, count * 8, c->w->stream);
+    op_encode(c, dv, 1, (int)count, (int)count, -1, c->w->ws_plain);
+    u64 *D = c->w->ws_ct3;
+    op_lift_ntt(c, c->w->ws_plain, 1, D);
     op_multiply_plain_ntt(c, ct, D, nullptr, 0, out, B);
-    if (rt_sync(c->stream)) rc = dev_fail("hhe_mask");
+    if (rt_sync(c->w->stream)) rc = dev_fail("hhe_mask");
     rt_free(dv);
     return rc;
 }
@@ -564,14 +603,14 @@ extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, u
     // gather block i of every sample into a contiguous batch, rotate by -128*i, accumulate
     EltArgs g;
     auto gather = [&](size_t i, u64 *dst) {
-        for (size_t s = 0; s < S; ++s) rt_d2d(dst + s * ctw, blocks + (s * nblocks + i) * ctw, ctw * 8, c->stream);
+        for (size_t s = 0; s < S; ++s) rt_d2d(dst + s * ctw, blocks + (s * nblocks + i) * ctw, ctw * 8, c->w->stream);
     };
     (void)g;
     gather(0, out);
     for (size_t i = 1; i < nblocks; ++i) {
-        gather(i, c->ws_ct[0]);
-        if ((rc = op_rotate_rows(c, c->ws_ct[0], -(int)(i * PASTA_T), c->ws_ct[1], S))) return rc;
-        op_add(c, out, c->ws_ct[1], out, S, 2);
+        gather(i, c->w->ws_ct[0]);
+        if ((rc = op_rotate_rows(c, c->w->ws_ct[0], -(int)(i * PASTA_T), c->w->ws_ct[1], S))) return rc;
+        op_add(c, out, c->w->ws_ct[1], out, S, 2);
     }
     return HHE_OK;
 }
@@ -582,11 +621,11 @@ extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, siz
     int rc = need(c, B);
     if (rc) return rc;
     const int L = c->L;
-    u64 *wb = c->ws_ct[0], *prod = c->ws_ct[1], *rot = c->ws_ct[2];
+    u64 *wb = c->w->ws_ct[0], *prod = c->w->ws_ct[1], *rot = c->w->ws_ct[2];
     op_elt(c, ELT_BCAST, nullptr, w, wb, B * 2 * L, 0, L, (int)(W * 2 * L));
-    op_multiply(c, vi, wb, c->ws_ct3, B);                      // packed_enc_multiply
-    if ((rc = op_relinearize(c, c->ws_ct3, prod, B))) return rc;  // CSP.cpp:306
-    rt_d2d(out, prod, B * c->ct_words() * 8, c->stream);
+    op_multiply(c, vi, wb, c->w->ws_ct3, B);                      // packed_enc_multiply
+    if ((rc = op_relinearize(c, c->w->ws_ct3, prod, B))) return rc;  // CSP.cpp:306
+    rt_d2d(out, prod, B * c->ct_words() * 8, c->w->stream);
     for (size_t i = 1; i < n_inputs; ++i) {                    // encrypted_vec_sum (sealhelper.cpp:379-392)
         if ((rc = op_rotate_rows(c, prod, -(int)i, rot, B))) return rc;
         op_add(c, out, rot, out, B, 2);

@@ -35,7 +35,6 @@ struct ModDev {
 enum NttLoadOp { LOAD_PLAIN = 0, LOAD_DIGIT = 1, LOAD_LIFT = 2, LOAD_RNEG = 3 };
 enum NttStoreOp {
     STORE_PLAIN = 0, STORE_MUL = 1, STORE_SCALE_T = 2, STORE_MAC = 3,
-    STORE_DIGIT_DIAG = 4,  // fwd: keep T; polys with J == I also accumulate T * permD into aux_acc
     STORE_RSP = 5,         // inv (special limb): v + floor(q_sp/2) mod q_sp
     STORE_KS1 = 6,         // inv: (v - r_1 + half) * q_sp^-1, written through the Galois map into aux_out
     STORE_KS0 = 7          // fwd: NTT-domain key-switch finish of c0 + permuted-frame diagonal MAC

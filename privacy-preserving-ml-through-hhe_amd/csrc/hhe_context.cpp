@@ -272,6 +272,14 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     c->ksc.half = kf.half;
     for (int j = 0; j < L; ++j) { c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j]; }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
+    if (const char *e = getenv("HHE_STREAMS")) c->nstreams = std::max(0, std::min(HHE_MAX_STREAMS, atoi(e)));
+    if (const char *e = getenv("HHE_CHUNK")) c->chunk = (size_t)std::max(1, atoi(e));
+    for (int s = 1; s <= c->nstreams; ++s) {
+        c->lanes[s].stream = rt_stream_create();
+        c->lanes[s].own_stream = true;
+        c->lanes[s].ev_done = rt_event_create();
+    }
+    c->ev_fork = rt_event_create();
     {   // a digit d_I < q_I may enter NTT_J unreduced when q_I < 4 q_J (butterfly inputs live in [0,4q))
         u64 qmax = 0, qmin = ~(u64)0;
         for (int i = 0; i < L; ++i) qmax = std::max(qmax, c->q[i]);
@@ -284,20 +292,52 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     return HHE_OK;
 }
 
-static void free_ws(hhe_ctx *c)
+static void free_lane(Lane &ln)
 {
-    rt_free(c->ws_T); rt_free(c->ws_S); rt_free(c->ws_d); rt_free(c->ws_ct3); rt_free(c->ws_plain); rt_free(c->ws_vals);
-    for (auto &p : c->ws_ct) { rt_free(p); p = nullptr; }
-    rt_free(c->bz_aq); rt_free(c->bz_bq); rt_free(c->bz_ab); rt_free(c->bz_bb); rt_free(c->bz_dq); rt_free(c->bz_db);
-    c->ws_T = c->ws_S = c->ws_d = c->ws_ct3 = c->ws_plain = c->ws_vals = nullptr;
-    c->bz_aq = c->bz_bq = c->bz_ab = c->bz_bb = c->bz_dq = c->bz_db = nullptr;
-    c->cap = 0;
+    rt_free(ln.ws_T); rt_free(ln.ws_S); rt_free(ln.ws_d); rt_free(ln.ws_ct3); rt_free(ln.ws_plain); rt_free(ln.ws_vals);
+    for (auto &p : ln.ws_ct) { rt_free(p); p = nullptr; }
+    rt_free(ln.bz_aq); rt_free(ln.bz_bq); rt_free(ln.bz_ab); rt_free(ln.bz_bb); rt_free(ln.bz_dq); rt_free(ln.bz_db);
+    ln.ws_T = ln.ws_S = ln.ws_d = ln.ws_ct3 = ln.ws_plain = ln.ws_vals = nullptr;
+    ln.bz_aq = ln.bz_bq = ln.bz_ab = ln.bz_bb = ln.bz_dq = ln.bz_db = nullptr;
+    ln.cap = 0;
+}
+static void sync_all(hhe_ctx *c)
+{
+    for (auto &ln : c->lanes)
+        if (&ln == &c->lanes[0] || ln.own_stream) rt_sync(ln.stream);
+}
+
+int lane_reserve(hhe_ctx *c, Lane &ln, size_t B)
+{
+    if (B == 0) { hhe_set_error("empty batch"); return HHE_ERR_INVALID; }
+    if (B <= ln.cap) return HHE_OK;
+    sync_all(c);
+    free_lane(ln);
+    const size_t n = c->n, L = c->L, K = c->K;
+    auto alloc = [&](size_t words) { return (u64 *)rt_malloc(words * 8); };
+    bool ok = true;
+    ok &= !!(ln.ws_T = alloc(B * L * K * n));
+    ok &= !!(ln.ws_S = alloc(B * 2 * K * n));
+    ok &= !!(ln.ws_d = alloc(B * L * n));
+    for (auto &p : ln.ws_ct) ok &= !!(p = alloc(B * 2 * L * n));
+    ok &= !!(ln.ws_ct3 = alloc(B * 3 * L * n));
+    ok &= !!(ln.ws_plain = alloc(B * n));
+    ok &= !!(ln.ws_vals = alloc(B * PASTA_T));
+    ok &= !!(ln.bz_aq = alloc(B * 2 * L * n));
+    ok &= !!(ln.bz_bq = alloc(B * 2 * L * n));
+    ok &= !!(ln.bz_ab = alloc(B * 2 * (L + 1) * n));
+    ok &= !!(ln.bz_bb = alloc(B * 2 * (L + 1) * n));
+    ok &= !!(ln.bz_dq = alloc(B * 3 * L * n));
+    ok &= !!(ln.bz_db = alloc(B * 3 * (L + 1) * n));
+    if (!ok) { free_lane(ln); hhe_set_error(std::string("workspace allocation failed: ") + rt_last_error()); return HHE_ERR_DEVICE; }
+    ln.cap = B;
+    return HHE_OK;
 }
 
 extern "C" void hhe_pasta3_clear_block_cache(hhe_ctx *c)
 {
     if (!c) return;
-    rt_sync(c->stream);
+    sync_all(c);
     for (auto &kv : c->blocks) { rt_free(kv.second.diag); rt_free(kv.second.pdiag); rt_free(kv.second.rc); rt_free(kv.second.bsgs); }
     c->blocks.clear();
 }
@@ -305,9 +345,14 @@ extern "C" void hhe_pasta3_clear_block_cache(hhe_ctx *c)
 extern "C" void hhe_ctx_destroy(hhe_ctx *c)
 {
     if (!c) return;
-    rt_sync(c->stream);
+    sync_all(c);
     hhe_pasta3_clear_block_cache(c);
-    free_ws(c);
+    for (auto &ln : c->lanes) {
+        free_lane(ln);
+        rt_event_destroy(ln.ev_done);
+        if (ln.own_stream) rt_stream_destroy(ln.stream);
+    }
+    rt_event_destroy(c->ev_fork);
     rt_free(c->d_rk);
     for (auto &kv : c->d_gk) rt_free(kv.second);
     rt_free(c->d_feistel_mask);
@@ -318,41 +363,29 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
 extern "C" int hhe_ctx_set_stream(hhe_ctx *c, void *s)
 {
     if (!c) return HHE_ERR_INVALID;
-    c->stream = (rt_stream)s;
+    c->lanes[0].stream = (rt_stream)s;
     return HHE_OK;
 }
 extern "C" int hhe_ctx_sync(hhe_ctx *c)
 {
     if (!c) return HHE_ERR_INVALID;
-    if (rt_sync(c->stream)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
+    if (rt_sync(c->lanes[0].stream)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
     return HHE_OK;
 }
 
 extern "C" int hhe_ctx_reserve(hhe_ctx *c, size_t B)
 {
     if (!c || B == 0) return HHE_ERR_INVALID;
-    if (B <= c->cap) return HHE_OK;
-    rt_sync(c->stream);
-    free_ws(c);
-    const size_t n = c->n, L = c->L, K = c->K;
-    auto alloc = [&](size_t words) { return (u64 *)rt_malloc(words * 8); };
-    bool ok = true;
-    ok &= !!(c->ws_T = alloc(B * L * K * n));
-    ok &= !!(c->ws_S = alloc(B * 2 * K * n));
-    ok &= !!(c->ws_d = alloc(B * L * n));
-    for (auto &p : c->ws_ct) ok &= !!(p = alloc(B * 2 * L * n));
-    ok &= !!(c->ws_ct3 = alloc(B * 3 * L * n));
-    ok &= !!(c->ws_plain = alloc(B * n));
-    ok &= !!(c->ws_vals = alloc(B * PASTA_T));
-    ok &= !!(c->bz_aq = alloc(B * 2 * L * n));
-    ok &= !!(c->bz_bq = alloc(B * 2 * L * n));
-    ok &= !!(c->bz_ab = alloc(B * 2 * (L + 1) * n));
-    ok &= !!(c->bz_bb = alloc(B * 2 * (L + 1) * n));
-    ok &= !!(c->bz_dq = alloc(B * 3 * L * n));
-    ok &= !!(c->bz_db = alloc(B * 3 * (L + 1) * n));
-    if (!ok) { free_ws(c); hhe_set_error(std::string("hhe_ctx_reserve: ") + rt_last_error()); return HHE_ERR_DEVICE; }
-    c->cap = B;
-    return HHE_OK;
+    // generic ops run whole batches on lane 0; the transciphering path works in chunks on the internal lanes
+    if (c->nstreams > 0) {
+        const size_t per = std::min(B, c->chunk);
+        for (int s = 1; s <= c->nstreams; ++s) {
+            int rc = lane_reserve(c, c->lanes[s], per);
+            if (rc) return rc;
+        }
+        return HHE_OK;
+    }
+    return lane_reserve(c, c->lanes[0], B);
 }
 
 extern "C" uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i)
@@ -371,7 +404,7 @@ extern "C" uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i)
 static int upload_key(hhe_ctx *c, u64 *&slot, const uint64_t *ksk)
 {
     if (!slot) slot = (u64 *)rt_malloc(c->ksk_words() * 8);
-    if (!slot || rt_h2d(slot, ksk, c->ksk_words() * 8, c->stream) || rt_sync(c->stream)) {
+    if (!slot || rt_h2d(slot, ksk, c->ksk_words() * 8, c->lanes[0].stream) || rt_sync(c->lanes[0].stream)) {
         hhe_set_error(std::string("key upload failed: ") + rt_last_error());
         return HHE_ERR_DEVICE;
     }
@@ -394,11 +427,11 @@ extern "C" void *hhe_malloc(size_t bytes) { return rt_malloc(bytes); }
 extern "C" void hhe_free(void *p) { rt_free(p); }
 extern "C" int hhe_copy_h2d(hhe_ctx *c, void *d, const void *h, size_t bytes)
 {
-    if (rt_h2d(d, h, bytes, c ? c->stream : nullptr) || rt_sync(c ? c->stream : nullptr)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
+    if (rt_h2d(d, h, bytes, c ? c->lanes[0].stream : nullptr) || rt_sync(c ? c->lanes[0].stream : nullptr)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
     return HHE_OK;
 }
 extern "C" int hhe_copy_d2h(hhe_ctx *c, void *h, const void *d, size_t bytes)
 {
-    if (rt_d2h(h, d, bytes, c ? c->stream : nullptr) || rt_sync(c ? c->stream : nullptr)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
+    if (rt_d2h(h, d, bytes, c ? c->lanes[0].stream : nullptr) || rt_sync(c ? c->lanes[0].stream : nullptr)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
     return HHE_OK;
 }

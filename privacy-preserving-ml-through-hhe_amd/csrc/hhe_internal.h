@@ -13,6 +13,25 @@ struct BlockTables {   // public per-(nonce, block index) data of one PASTA bloc
     u64 *bsgs = nullptr;  // [4][128][L][N] babystep-giantstep variant of diag (lazy)
 };
 
+constexpr int HHE_MAX_STREAMS = 4;
+struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `cap` ciphertexts)
+    rt_stream stream = nullptr;
+    void *ev_done = nullptr;
+    bool own_stream = false;
+    size_t cap = 0;
+    u64 *ws_T = nullptr;     // [B][L][K][N]
+    u64 *ws_S = nullptr;     // [B][2][K][N]
+    u64 *ws_d = nullptr;     // [B][L][N]
+    u64 *ws_ct[4] = {nullptr, nullptr, nullptr, nullptr};  // [B][2][L][N] each
+    u64 *ws_ct3 = nullptr;   // [B][3][L][N]
+    u64 *ws_plain = nullptr; // [B][N]
+    u64 *ws_vals = nullptr;  // [B][128]
+    u64 *bz_aq = nullptr, *bz_bq = nullptr;  // [B][2][L][N]
+    u64 *bz_ab = nullptr, *bz_bb = nullptr;  // [B][2][L+1][N]
+    u64 *bz_dq = nullptr;    // [B][3][L][N]
+    u64 *bz_db = nullptr;    // [B][3][L+1][N]
+};
+
 struct hhe_ctx {
     int logn = 0, K = 0, L = 0, device = 0;
     size_t n = 0;
@@ -23,7 +42,6 @@ struct hhe_ctx {
     std::vector<u64> roots;        // psi per coefficient prime
     int nmod = 0;                  // K + (L+1) + 1
     int mod_t = 0;                 // index of the plain modulus
-    rt_stream stream = nullptr;
     int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
     int matmul_mode = 1;           // 1: fused 20-transform pipeline (default), 0: op-by-op schedule
     KsConsts ksc{};
@@ -47,19 +65,13 @@ struct hhe_ctx {
     std::map<u64, BlockTables> blocks;
     u64 *d_feistel_mask = nullptr;  // [L][N] NTT form of the sbox_feistel mask plaintext
 
-    // workspace
-    size_t cap = 0;
-    u64 *ws_T = nullptr;     // [B][L][K][N]
-    u64 *ws_S = nullptr;     // [B][2][K][N]
-    u64 *ws_d = nullptr;     // [B][L][N]
-    u64 *ws_ct[4] = {nullptr, nullptr, nullptr, nullptr};  // [B][2][L][N] each
-    u64 *ws_ct3 = nullptr;   // [B][3][L][N]
-    u64 *ws_plain = nullptr; // [B][N]
-    u64 *ws_vals = nullptr;  // [B][128]
-    u64 *bz_aq = nullptr, *bz_bq = nullptr;  // [B][2][L][N]
-    u64 *bz_ab = nullptr, *bz_bb = nullptr;  // [B][2][L+1][N]
-    u64 *bz_dq = nullptr;    // [B][3][L][N]
-    u64 *bz_db = nullptr;    // [B][3][L+1][N]
+    // execution lanes: lane 0 runs on the caller's stream (generic ops); lanes 1.. are internal streams that
+    // the transciphering path uses to process chunks of a batch concurrently (each with its own workspace)
+    Lane lanes[1 + HHE_MAX_STREAMS];
+    Lane *w = &lanes[0];
+    int nstreams = 2;      // internal streams used by hhe_pasta3_transcipher (0 = caller's stream only)
+    size_t chunk = 32;     // items per chunk: keeps a chunk's digit transforms inside the 256 MiB Infinity Cache
+    void *ev_fork = nullptr;
 
     size_t ct_words() const { return (size_t)2 * L * n; }
     size_t ksk_words() const { return (size_t)L * 2 * K * n; }
@@ -79,3 +91,4 @@ u32 galois_elt_from_step(const hhe_ctx *c, int step);
 void pasta3_block_randomness(u64 t, u64 nonce, u64 block, u64 *mats, u64 *rcs);
 
 void hhe_set_error(const std::string &msg);
+int lane_reserve(hhe_ctx *c, Lane &ln, size_t B);

@@ -12,15 +12,28 @@
 #pragma once
 #include "hhe_modarith.h"
 
+#ifndef HHE_NTT_VARIANT
+#define HHE_NTT_VARIANT 0
+#endif
 constexpr int NTT_THREADS = 256;
-constexpr int NTT_TILE_LOG = 12;                    // 4096 points per tile
-constexpr int NTT_LDS_ELEMS = (1 << NTT_TILE_LOG) + 512;  // rows of pitch C+1
-
+#if HHE_NTT_VARIANT == 0
+// 4096-point tiles, radix-16/8 register rounds: 16 points per thread, ~128 VGPRs, 36 KiB LDS -> 4 waves/SIMD
+constexpr int NTT_TILE_LOG = 12;
 template <int LOGM> struct NttSched;  // register-radix schedule per sub-transform size
 template <> struct NttSched<5> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
 template <> struct NttSched<6> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
 template <> struct NttSched<7> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 4 : 3; } };
 template <> struct NttSched<8> { static constexpr int R = 2; static constexpr int rho(int i) { return 4; } };
+#else
+// 2048-point tiles, radix-8/4 register rounds: 8 points per thread, <=64 VGPRs, 18 KiB LDS -> 8 waves/SIMD
+constexpr int NTT_TILE_LOG = 11;
+template <int LOGM> struct NttSched;
+template <> struct NttSched<5> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
+template <> struct NttSched<6> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
+template <> struct NttSched<7> { static constexpr int R = 3; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
+template <> struct NttSched<8> { static constexpr int R = 3; static constexpr int rho(int i) { return i == 2 ? 2 : 3; } };
+#endif
+constexpr int NTT_LDS_ELEMS = (1 << NTT_TILE_LOG) + 512;  // rows of pitch C+1
 
 HD u32 bitrev_n(u32 v, int bits)
 {
@@ -65,6 +78,18 @@ template <bool STRIDED> HD int ntt_gidx(const NttGeom &g, int x, int lane)
     return (g.tile * g.C + lane) * g.M + x;
 }
 
+struct alignas(16) U2 { u64 a, b; };
+HD U2 ld2(const u64 *p) { return *reinterpret_cast<const U2 *>(p); }   // 16 B per lane: the coalescing sweet spot
+HD void st2(u64 *p, U2 v) { *reinterpret_cast<U2 *>(p) = v; }
+
+// element pair handled by one lane in the load/store phases: (x, lane) and its neighbour in global memory
+template <bool STRIDED> HD void ntt_pair(const NttArgs &a, const NttGeom &g, int e2, int &x, int &lane, int &gi, int &lds0, int &lds1)
+{
+    if (STRIDED) { lane = (e2 & ((g.C >> 1) - 1)) << 1; x = e2 >> (a.logc - 1); lds0 = x * g.pitch + lane; lds1 = lds0 + 1; }
+    else { x = (e2 & ((g.M >> 1) - 1)) << 1; lane = e2 >> (a.logm - 1); lds0 = x * g.pitch + lane; lds1 = lds0 + g.pitch; }
+    gi = ntt_gidx<STRIDED>(g, x, lane);
+}
+
 template <bool STRIDED, bool INVERSE>
 HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
@@ -76,18 +101,27 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
         const int ip = a.src_item_polys > 0 ? a.src_item_polys : a.count;
         src = a.src + (size_t)(g.poly / ip) * a.src_item_stride + (size_t)((g.poly % ip) / a.src_div) * g.n;
     } else src = a.dst + (size_t)g.poly * g.n;
-    const int E = g.M * g.C;
-    for (int e = tid; e < E; e += NTT_THREADS) {
-        int x, lane;
-        if (STRIDED) { lane = e & (g.C - 1); x = e >> a.logc; }
-        else { x = e & (g.M - 1); lane = e >> a.logm; }
-        u64 v = src[ntt_gidx<STRIDED>(g, x, lane)];
+    const int E2 = (g.M * g.C) >> 1;
+    for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) {
+        int x, lane, gi, l0, l1;
+        ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
+        U2 v;
+        if (FIRST && a.load_op == 99) { v.a = (u64)(x * 131 + lane); v.b = v.a + 1; }  // timing probe (no global read)
+        else v = ld2(src + gi);
         if (FIRST) {
-            if (a.load_op == LOAD_DIGIT) { if (a.digit_reduce) v = reduce64(v, m); }
-            else if (a.load_op == LOAD_LIFT) v = (v >= ((a.t + 1) >> 1)) ? v + (m.q - a.t) : v;
-            else if (a.load_op == LOAD_RNEG) v = submod(reduce64(v, m), a.ks.half_mod[g.poly % a.L], m.q);
+            if (a.load_op == LOAD_DIGIT) { if (a.digit_reduce) { v.a = reduce64(v.a, m); v.b = reduce64(v.b, m); } }
+            else if (a.load_op == LOAD_LIFT) {
+                const u64 thr = (a.t + 1) >> 1, inc = m.q - a.t;
+                v.a = (v.a >= thr) ? v.a + inc : v.a;
+                v.b = (v.b >= thr) ? v.b + inc : v.b;
+            } else if (a.load_op == LOAD_RNEG) {
+                const u64 h = a.ks.half_mod[g.poly % a.L];
+                v.a = submod(reduce64(v.a, m), h, m.q);
+                v.b = submod(reduce64(v.b, m), h, m.q);
+            }
         }
-        lds[x * g.pitch + lane] = v;
+        lds[l0] = v.a;
+        lds[l1] = v.b;
     }
 }
 
@@ -164,69 +198,75 @@ HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds
     const ModDev &m = a.mods[g.mod_index];
     const u64 q = m.q, q2 = q << 1;
     u64 *dst = a.dst + (size_t)g.poly * g.n;
-    const int E = g.M * g.C;
-    for (int e = tid; e < E; e += NTT_THREADS) {
-        int x, lane;
-        if (STRIDED) { lane = e & (g.C - 1); x = e >> a.logc; }
-        else { x = e & (g.M - 1); lane = e >> a.logm; }
-        const int gi = ntt_gidx<STRIDED>(g, x, lane);
-        u64 v = lds[x * g.pitch + lane];
-        if (LAST) {
-            if (INVERSE) {
-                if (a.store_op == STORE_SCALE_T) v = shoup_lazy(v, m.ninv_t, m.ninv_t_s, q);
-                else v = shoup_lazy(v, m.ninv, m.ninv_s, q);
-                v -= (v >= q) ? q : 0;
-                if (a.store_op == STORE_RSP) v = addmod(v, a.ks.half, q);
-                else if (a.store_op == STORE_KS1) {
-                    const int j = g.poly % a.L;
-                    const size_t item = g.poly / a.L;
-                    const u64 rj = reduce64(a.aux_r[(item * 2 + 1) * g.n + gi], m);
-                    v = addmod(submod(v, rj, q), a.ks.half_mod[j], q);
-                    v = shoup_mul(v, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
-                    u32 idx = (u32)gi;
+    const size_t pbase = (size_t)g.poly * g.n;
+    const int E2 = (g.M * g.C) >> 1;
+    for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) {
+        int x, lane, gi, l0, l1;
+        ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
+        u64 v[2] = {lds[l0], lds[l1]};
+        if (a.store_op == 99) { if (v[0] == 0x123456789abcdefULL) dst[gi] = v[0]; continue; }  // timing probe (no global write)
+        if (!LAST) { st2(dst + gi, U2{v[0], v[1]}); continue; }
+        if (INVERSE) {
+            const bool st = a.store_op == STORE_SCALE_T;
+            for (int k = 0; k < 2; k++) {
+                v[k] = shoup_lazy(v[k], st ? m.ninv_t : m.ninv, st ? m.ninv_t_s : m.ninv_s, q);
+                v[k] -= (v[k] >= q) ? q : 0;
+            }
+            if (a.store_op == STORE_RSP) { v[0] = addmod(v[0], a.ks.half, q); v[1] = addmod(v[1], a.ks.half, q); }
+            else if (a.store_op == STORE_KS1) {
+                const int j = g.poly % a.L;
+                const size_t item = g.poly / a.L;
+                const U2 r = ld2(a.aux_r + (item * 2 + 1) * g.n + gi);
+                const u64 rr[2] = {r.a, r.b};
+                for (int k = 0; k < 2; k++) {
+                    u64 o = addmod(submod(v[k], reduce64(rr[k], m), q), a.ks.half_mod[j], q);
+                    o = shoup_mul(o, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
+                    u32 idx = (u32)(gi + k);
                     if (a.gal_elt) {
-                        const u64 raw = (u64)gi * a.gal_elt;
+                        const u64 raw = (u64)(gi + k) * a.gal_elt;
                         idx = (u32)(raw & (g.n - 1));
-                        if ((raw >> a.logn) & 1) v = negmod(v, q);
+                        if ((raw >> a.logn) & 1) o = negmod(o, q);
                     }
-                    a.aux_out[(size_t)g.poly * g.n + idx] = v;
+                    a.aux_out[pbase + idx] = o;
+                }
+                continue;
+            }
+        } else {
+            for (int k = 0; k < 2; k++) {
+                v[k] -= (v[k] >= q2) ? q2 : 0;
+                v[k] -= (v[k] >= q) ? q : 0;
+            }
+            if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
+                const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
+                const U2 d = ld2(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);
+                v[0] = mulmod(v[0], d.a, m);
+                v[1] = mulmod(v[1], d.b, m);
+                if (a.store_op == STORE_MAC) {
+                    U2 acc = ld2(a.acc + pbase + gi);
+                    acc.a = addmod(acc.a, v[0], q);
+                    acc.b = addmod(acc.b, v[1], q);
+                    st2(a.acc + pbase + gi, acc);
                     continue;
                 }
-            } else {
-                v -= (v >= q2) ? q2 : 0;
-                v -= (v >= q) ? q : 0;
-                if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
-                    const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
-                    v = mulmod(v, mp[a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi], m);
-                    if (a.store_op == STORE_MAC) {
-                        u64 *ap = a.acc + (size_t)g.poly * g.n + gi;
-                        *ap = addmod(*ap, v, q);
-                        continue;
-                    }
-                } else if (a.store_op == STORE_DIGIT_DIAG) {
-                    const int J = g.poly % a.K, I = (g.poly / a.K) % a.L;
-                    if (I == J) {
-                        const size_t item = g.poly / (a.K * a.L);
-                        const u64 d = a.mul_ptrs[item][a.mul_shift + (size_t)I * g.n + gi];
-                        u64 *ap = a.acc + (item * a.L + I) * g.n + gi;
-                        *ap = addmod(*ap, mulmod(v, d, m), q);
-                    }
-                } else if (a.store_op == STORE_KS0) {
-                    const int j = g.poly % a.L;
-                    const size_t item = g.poly / a.L;
-                    const u32 pi = ntt_perm_index((u32)gi, a.logn, a.gal_elt);
-                    const u64 gth = a.aux_in[(size_t)g.poly * g.n + pi];
-                    const u64 d = a.mul_ptrs[item][a.mul_shift + (size_t)j * g.n + gi];
-                    u64 *ap = a.acc + (size_t)g.poly * g.n + gi;
-                    *ap = addmod(*ap, mulmod(gth, d, m), q);
-                    const u64 s0 = a.aux_r[((item * 2 + 0) * a.K + j) * g.n + gi];
-                    const u64 o = shoup_mul(submod(s0, v, q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
-                    a.aux_out[(size_t)g.poly * g.n + gi] = addmod(gth, o, q);
-                    continue;
-                }
+            } else if (a.store_op == STORE_KS0) {
+                const int j = g.poly % a.L;
+                const size_t item = g.poly / a.L;
+                const U2 d = ld2(a.mul_ptrs[item] + a.mul_shift + (size_t)j * g.n + gi);
+                const U2 s0 = ld2(a.aux_r + ((item * 2 + 0) * a.K + j) * g.n + gi);
+                U2 acc = ld2(a.acc + pbase + gi);
+                const u64 g0 = a.aux_in[pbase + ntt_perm_index((u32)gi, a.logn, a.gal_elt)];
+                const u64 g1 = a.aux_in[pbase + ntt_perm_index((u32)gi + 1, a.logn, a.gal_elt)];
+                acc.a = addmod(acc.a, mulmod(g0, d.a, m), q);
+                acc.b = addmod(acc.b, mulmod(g1, d.b, m), q);
+                st2(a.acc + pbase + gi, acc);
+                U2 o;
+                o.a = addmod(g0, shoup_mul(submod(s0.a, v[0], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
+                o.b = addmod(g1, shoup_mul(submod(s0.b, v[1], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
+                st2(a.aux_out + pbase + gi, o);
+                continue;
             }
         }
-        dst[gi] = v;
+        st2(dst + gi, U2{v[0], v[1]});
     }
 }
 

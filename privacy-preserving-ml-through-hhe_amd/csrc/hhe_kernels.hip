@@ -31,6 +31,22 @@ int rt_d2h(void *d, const void *s, size_t n, rt_stream st) { return rt_check(hip
 int rt_d2d(void *d, const void *s, size_t n, rt_stream st) { return rt_check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st), "d2d"); }
 int rt_memset(void *d, int v, size_t n, rt_stream st) { return rt_check(hipMemsetAsync(d, v, n, (hipStream_t)st), "memset"); }
 int rt_sync(rt_stream st) { return rt_check(hipStreamSynchronize((hipStream_t)st), "sync"); }
+rt_stream rt_stream_create()
+{
+    hipStream_t s = nullptr;
+    if (rt_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    return (rt_stream)s;
+}
+void rt_stream_destroy(rt_stream s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+void *rt_event_create()
+{
+    hipEvent_t e = nullptr;
+    if (rt_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return nullptr;
+    return (void *)e;
+}
+void rt_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int rt_event_record(void *ev, rt_stream s) { return rt_check(hipEventRecord((hipEvent_t)ev, (hipStream_t)s), "hipEventRecord"); }
+int rt_stream_wait_event(rt_stream s, void *ev) { return rt_check(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0), "hipStreamWaitEvent"); }
 
 // ---------------------------------------------------------------- NTT
 template <int LOGM, bool STRIDED, bool INVERSE, int R>
@@ -58,8 +74,13 @@ struct NttRounds {
     }
 };
 
+#if HHE_NTT_VARIANT == 0
+#define NTT_MIN_WAVES 1
+#else
+#define NTT_MIN_WAVES 2
+#endif
 template <int LOGM, bool STRIDED, bool INVERSE>
-__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttArgs a)
+__global__ void __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES * 4) ntt_pass_kernel(NttArgs a)
 {
     __shared__ u64 lds[NTT_LDS_ELEMS];
     ntt_body_load<STRIDED, INVERSE>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);

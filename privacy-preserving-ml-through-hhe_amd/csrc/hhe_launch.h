@@ -16,6 +16,12 @@ int rt_d2h(void *dst, const void *src, size_t bytes, rt_stream s);
 int rt_d2d(void *dst, const void *src, size_t bytes, rt_stream s);
 int rt_memset(void *dst, int v, size_t bytes, rt_stream s);
 int rt_sync(rt_stream s);
+rt_stream rt_stream_create();
+void rt_stream_destroy(rt_stream s);
+void *rt_event_create();
+void rt_event_destroy(void *ev);
+int rt_event_record(void *ev, rt_stream s);
+int rt_stream_wait_event(rt_stream s, void *ev);
 const char *rt_last_error();
 
 // kernels (all asynchronous on `s`)

@@ -20,6 +20,12 @@ int rt_d2h(void *d, const void *s, size_t n, rt_stream) { memcpy(d, s, n); retur
 int rt_d2d(void *d, const void *s, size_t n, rt_stream) { memmove(d, s, n); return 0; }
 int rt_memset(void *d, int v, size_t n, rt_stream) { memset(d, v, n); return 0; }
 int rt_sync(rt_stream) { return 0; }
+rt_stream rt_stream_create() { static int dummy[8]; static int n = 0; return (rt_stream)&dummy[(n++) & 7]; }
+void rt_stream_destroy(rt_stream) {}
+void *rt_event_create() { static int ev; return &ev; }
+void rt_event_destroy(void *) {}
+int rt_event_record(void *, rt_stream) { return 0; }
+int rt_stream_wait_event(rt_stream, void *) { return 0; }
 
 template <int LOGM, bool STRIDED, bool INVERSE, int I, int S0>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
