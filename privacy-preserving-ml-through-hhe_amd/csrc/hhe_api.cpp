@@ -386,6 +386,7 @@ extern "C" int hhe_ntt(hhe_ctx *c, uint64_t *polys, size_t count, int mod_base, 
         const int p = atoi(probe);
         if (p & 1) a.load_op = 99;
         if (p & 2) a.store_op = 99;
+        a.probe = p;
         k_ntt(a, inverse != 0, c->w->stream);
         return HHE_OK;
     }

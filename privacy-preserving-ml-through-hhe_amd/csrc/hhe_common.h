@@ -62,6 +62,7 @@ struct NttArgs {
     int src_item_polys;   // polys of one batch item in p-space (0 => whole batch is one item)
     size_t src_item_stride;  // words between items in src
     int load_op, store_op;
+    int probe;         // timing probes (tools/ntt_micro.py): bit 2 = skip the butterflies
     int digit_reduce;  // DIGIT: 1 if some q_I >= 4*q_J (else the lazy butterflies absorb the unreduced residue)
     u64 t;          // LIFT: plain modulus
     // STORE_MUL / STORE_MAC multiplier (NTT form): (mul_ptrs ? mul_ptrs[p / mul_item_polys] : mul)

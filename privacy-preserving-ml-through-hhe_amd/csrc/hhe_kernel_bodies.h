@@ -324,33 +324,40 @@ HD void perm_body(const PermArgs &a, size_t gid)
     else *o = v;
 }
 
-// key-switch inner product: gid over [B][K][N]
+// key-switch inner product: gid over [B][K][N/2], two adjacent coefficients per lane (16-B accesses)
 HD void ks_mac_body(const KsMacArgs &a, size_t gid)
 {
     const size_t n = (size_t)1 << a.logn;
-    const size_t i = gid & (n - 1);
-    const size_t bj = gid >> a.logn;
+    const size_t i = (gid & ((n >> 1) - 1)) << 1;
+    const size_t bj = gid >> (a.logn - 1);
     const int J = (int)(bj % a.K);
     const size_t b = bj / a.K;
     if (b >= (size_t)a.B) return;
     const ModDev &m = a.mods[J];
-    Acc128 s0 = {0, 0}, s1 = {0, 0};
-    u64 r0 = 0, r1 = 0;
+    Acc128 s0[2] = {{0, 0}, {0, 0}}, s1[2] = {{0, 0}, {0, 0}};
     for (int I = 0; I < a.L; I++) {
-        const u64 t = a.T[((b * a.L + I) * a.K + J) * n + i];
+        const U2 t = ld2(a.T + ((b * a.L + I) * a.K + J) * n + i);
+        const U2 k0 = ld2(a.key + (((size_t)I * 2 + 0) * a.K + J) * n + i);
+        const U2 k1 = ld2(a.key + (((size_t)I * 2 + 1) * a.K + J) * n + i);
         if (a.acc && I == J) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product
+            const U2 d = ld2(a.mul_ptrs[b] + a.mul_shift + (size_t)J * n + i);
             u64 *ap = a.acc + (b * a.L + J) * n + i;
-            *ap = addmod(*ap, mulmod(t, a.mul_ptrs[b][a.mul_shift + (size_t)J * n + i], m), m.q);
+            U2 acc = ld2(ap);
+            acc.a = addmod(acc.a, mulmod(t.a, d.a, m), m.q);
+            acc.b = addmod(acc.b, mulmod(t.b, d.b, m), m.q);
+            st2(ap, acc);
         }
-        acc_mac(s0, t, a.key[(((size_t)I * 2 + 0) * a.K + J) * n + i]);
-        acc_mac(s1, t, a.key[(((size_t)I * 2 + 1) * a.K + J) * n + i]);
+        acc_mac(s0[0], t.a, k0.a); acc_mac(s0[1], t.b, k0.b);
+        acc_mac(s1[0], t.a, k1.a); acc_mac(s1[1], t.b, k1.b);
         if ((I & 3) == 3) {  // q < 2^61: four products stay below 2^124
-            r0 = barrett128(s0.lo, s0.hi, m); s0.lo = r0; s0.hi = 0;
-            r1 = barrett128(s1.lo, s1.hi, m); s1.lo = r1; s1.hi = 0;
+            for (int k = 0; k < 2; k++) {
+                s0[k].lo = barrett128(s0[k].lo, s0[k].hi, m); s0[k].hi = 0;
+                s1[k].lo = barrett128(s1[k].lo, s1[k].hi, m); s1[k].hi = 0;
+            }
         }
     }
-    a.S[((b * 2 + 0) * a.K + J) * n + i] = barrett128(s0.lo, s0.hi, m);
-    a.S[((b * 2 + 1) * a.K + J) * n + i] = barrett128(s1.lo, s1.hi, m);
+    st2(a.S + ((b * 2 + 0) * a.K + J) * n + i, U2{barrett128(s0[0].lo, s0[0].hi, m), barrett128(s0[1].lo, s0[1].hi, m)});
+    st2(a.S + ((b * 2 + 1) * a.K + J) * n + i, U2{barrett128(s1[0].lo, s1[0].hi, m), barrett128(s1[1].lo, s1[1].hi, m)});
 }
 
 // key-switch mod-down by the special prime with rounding: gid over [B][2][L][N]
