@@ -132,6 +132,10 @@ def main():
     if rank == 0:
         A = a_block_bytes(n, L, K)
         path_ms = dev_ms / args.steps
+        traffic = None  # HBM-side bytes per launch of the path from rocprofv3 PMC passes (tools/pmc_traffic.py)
+        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_b256.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf))["traffic_bytes_per_transciphering"] * B
         achieved = A * B / (path_ms * 1e-3) / 1e9
         res = {
             "metric": "PASTA-3 transcipherings/sec (N=2^15, 4 RNS limbs)", "value": value, "unit": "transcipherings/s",
@@ -141,7 +145,8 @@ def main():
                                    f"batch-{B} independent 128-word PASTA-3 blocks per GPU, block counter 0",
                        "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",
+                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                         "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",
                          "algorithmic_bytes_per_unit": A, "units_per_launch": B, "launch_ms": path_ms,
                          "dominant_kernel": {"name": "ntt_pass_kernel (forward, both passes)", "polys": npoly,
                                              "algorithmic_bytes": ntt_alg, "ms": ntt_ms,
