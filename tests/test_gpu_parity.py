@@ -119,3 +119,81 @@ def test_fc_row_and_flatten_small(orc, api, lib, mem):
     fo = mem.empty((1,) + O.ct_shape)
     X.flatten(mem.to_dev(blocks[None]), 3, fo, 1)
     assert (mem.to_host(fo)[0] == O.flatten(blocks, S.gk)).all()
+
+
+BFV_DEFAULT_16384 = [281474976546817, 281474976317441, 281474975662081, 562949952798721, 562949952700417,
+                     562949952274433, 562949951979521, 562949951881217, 562949951619073]
+
+
+def test_config1_dry_run_mnist_sample_end_to_end(orc, api, lib, mem):
+    """BASELINE config 1 shape (reference defaults: t=65537, N=16384, BFVDefault 9 primes): one 784-word 2-bit
+    sample -> 7 transcipherings -> mask (last block) -> flatten -> one FC row (multiply + relinearize +
+    encrypted_vec_sum over all default Galois keys), checked the way the reference checks itself
+    (hhe_pktnn_examples.cpp:639-648, 692-699): decrypt == input, FC == plain integer matmul."""
+    S = Setup.__new__(Setup)
+    S.t, S.logn, S.n, S.q = T, 14, 1 << 14, BFV_DEFAULT_16384
+    S.O = O = orc.Oracle(14, S.q, T)
+    S.sk = O.keygen_secret(1)
+    S.pk = O.keygen_public(S.sk, 2)
+    S.rk = O.keygen_relin(S.sk, 3)
+    steps = [-1, 0, 128] + [-128 * i for i in range(1, 7)]
+    elts = list(dict.fromkeys([int(e) for e in O.galois_elts_all()] + [O.galois_elt(s) for s in steps]))
+    S.gk = O.keygen_galois(S.sk, elts, 7)
+    S.key = np.array([(i * 2654435761 + 12345) % T for i in range(256)], dtype=np.uint64)
+    S.enc_key = O.encrypt(S.pk, O.pasta_pack_key(S.key), 11)
+    X = api.Context(S.logn, S.q, S.t, lib=lib)
+    S.load_keys(X)
+    rng = np.random.default_rng(7)
+    n_in = 784
+    pix = rng.integers(0, 4, n_in)            # 2-bit quantised image
+    w = rng.integers(-1, 2, n_in)             # ternary weight row
+    cw, ncw = S.sym_blocks(orc, pix)
+    nb = cw.shape[0]
+    assert nb == 7 and ncw[-1] == 16
+    blocks = mem.empty((nb,) + O.ct_shape)
+    X.transcipher(mem.to_dev(S.enc_key), cw, ncw, list(range(nb)), blocks)
+    hb = mem.to_host(blocks)
+    # ragged last block, bit for bit against the oracle
+    assert (hb[6] == O.transcipher_block(S.enc_key, S.rk, S.gk, cw[6, :16], 6)).all()
+    # mask the last block (rem = 16), flatten, decrypt == input
+    last = mem.to_dev(hb[6:7])
+    X.mask(last, np.ones(16, np.uint64), last, 1)
+    hb2 = hb.copy()
+    hb2[6] = mem.to_host(last)[0]
+    flat = mem.empty((1,) + O.ct_shape)
+    X.flatten(mem.to_dev(hb2[None]), nb, flat, 1)
+    dec = O.decode(O.decrypt(S.sk, mem.to_host(flat)[0]))
+    assert (dec[:n_in] == pix).all()
+    # FC row
+    wc = O.encrypt(S.pk, O.encode(w), 22)
+    out = mem.empty((1,) + O.ct_shape)
+    X.fc_row(flat, mem.to_dev(wc[None]), 1, n_in, out, 1)
+    res = O.decode(O.decrypt(S.sk, mem.to_host(out)[0]))
+    assert int(res[n_in - 1]) == int(np.dot(pix, w)) % T
+    assert O.noise_budget(S.sk, mem.to_host(out)[0], 8) > 0
+
+
+def test_config5_n65536_six_primes_rotation_chain_and_multiply(orc, api, lib, mem):
+    """BASELINE config 5 shape: N=2^16, 6x60-bit primes, t=8088322049; key-switch heavy chain, ciphertext parity."""
+    t = 8088322049
+    S = Setup(orc, 16, [60] * 6, t=t)
+    O = S.O
+    X = api.Context(S.logn, S.q, t, lib=lib)
+    S.load_keys(X)
+    rng = np.random.default_rng(5)
+    B = 2
+    cts = np.stack([O.encrypt(S.pk, O.encode(rng.integers(0, 1 << 30, O.n)), 40 + b) for b in range(B)])
+    d = mem.to_dev(cts)
+    refs = [c.copy() for c in cts]
+    for _ in range(4):
+        X.rotate_rows(d, -1, d, B)
+        refs = [O.rotate_rows(r, -1, S.gk)[0] for r in refs]
+    h = mem.to_host(d)
+    for b in range(B):
+        assert (h[b] == refs[b]).all()
+    o3 = mem.empty((B, 3, O.L, O.n))
+    X.multiply(d, d, o3, B)
+    assert (mem.to_host(o3)[0] == O.multiply(refs[0], refs[0])).all()
+    out = mem.empty((B,) + O.ct_shape)
+    X.relinearize(o3, out, B)
+    assert (mem.to_host(out)[0] == O.relinearize(mem.to_host(o3)[0], S.rk)).all()
