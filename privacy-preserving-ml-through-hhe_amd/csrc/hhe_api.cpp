@@ -254,6 +254,79 @@ int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
     return HHE_OK;
 }
 
+// babystep-giantstep multiplier tables of one block (lazy): same pipeline as `diag` with the rearranged diagonals
+int ensure_bsgs_tables(hhe_ctx *c, u64 block, BlockTables *bt)
+{
+    if (bt->bsgs) return HHE_OK;
+    const size_t n = c->n;
+    const int L = c->L;
+    const size_t ndiag = (size_t)(PASTA_R + 1) * PASTA_T;
+    std::vector<u64> mats((size_t)(PASTA_R + 1) * 2 * PASTA_T * PASTA_T), rcs((size_t)(PASTA_R + 1) * 2 * PASTA_T);
+    pasta3_block_randomness(c->t, PASTA_NONCE, block, mats.data(), rcs.data());
+    u64 *d_mats = (u64 *)rt_malloc(mats.size() * 8), *slots = (u64 *)rt_malloc(ndiag * n * 8);
+    bt->bsgs = (u64 *)rt_malloc(ndiag * L * n * 8);
+    if (!d_mats || !slots || !bt->bsgs) return dev_fail("bsgs table alloc");
+    rt_h2d(d_mats, mats.data(), mats.size() * 8, c->w->stream);
+    rt_memset(slots, 0, ndiag * n * 8, c->w->stream);
+    BsgsDiagArgs d;
+    memset(&d, 0, sizeof(d));
+    d.mats = d_mats; d.out = slots; d.slot_map = c->d_slot_map; d.logn = c->logn; d.n1 = 16;
+    k_bsgs_diag(d, c->w->stream);
+    op_ntt(c, slots, ndiag, c->mod_t, 1, true);
+    op_lift_ntt(c, slots, ndiag, bt->bsgs);
+    if (rt_sync(c->w->stream)) return dev_fail("bsgs tables");
+    rt_free(d_mats); rt_free(slots);
+    return HHE_OK;
+}
+
+// PASTA_SEAL::babystep_giantstep (pasta_3_seal.cpp:267-366), N1 = 16, N2 = 8 (pasta_3_seal.h:35-36): 15 baby
+// rotations by -1, 8 inner sums of 16 plain products (accumulated in the NTT domain), 7 giant
+// rotations by -16k.  State in ws_ct[0].
+int matmul_bsgs(hhe_ctx *c, int layer, const u64 *const *d_bsgs_ptrs, size_t B)
+{
+    constexpr int N1 = 16, N2 = 8;
+    const int L = c->L;
+    const size_t n = c->n, ctw = c->ct_words();
+    Lane &w = *c->w;
+    if (w.rot_cap < B) {
+        rt_sync(w.stream);
+        rt_free(w.ws_rot);
+        w.ws_rot = (u64 *)rt_malloc(B * N1 * ctw * 8);
+        if (!w.ws_rot) return dev_fail("bsgs workspace");
+        w.rot_cap = B;
+    }
+    u64 *state = w.ws_ct[0], *inner = w.ws_ct[1], *scratch = w.ws_ct[2], *outer = w.ws_ct3;  // ct3 holds [B][3].. >= [B][2]
+    if (n / 2 != PASTA_T) {
+        int rc = op_rotate_rows(c, state, PASTA_T, scratch, B);
+        if (rc) return rc;
+        op_add(c, state, scratch, state, B, 2);
+    }
+    // rot[j] laid out [j][B][2][L][N]
+    rt_d2d(w.ws_rot, state, B * ctw * 8, w.stream);
+    for (int j = 1; j < N1; ++j) {
+        int rc = op_rotate_rows(c, w.ws_rot + (size_t)(j - 1) * B * ctw, -1, w.ws_rot + (size_t)j * B * ctw, B);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < N2; ++k) {
+        rt_memset(inner, 0, B * ctw * 8, w.stream);
+        for (int j = 0; j < N1; ++j) {
+            NttArgs a = ntt_args(c, w.ws_rot + (size_t)j * B * ctw, scratch, B * 2 * L, 0, L);
+            a.store_op = STORE_MAC; a.mul_ptrs = d_bsgs_ptrs; a.mul_shift = ((size_t)layer * PASTA_T + k * N1 + j) * L * n;
+            a.mul_cycle = L; a.mul_item_polys = 2 * L; a.acc = inner;
+            k_ntt(a, false, w.stream);
+        }
+        op_ntt(c, inner, B * 2 * L, 0, L, true);
+        if (k == 0) rt_d2d(outer, inner, B * ctw * 8, w.stream);
+        else {
+            int rc = op_rotate_rows(c, inner, -k * N1, inner, B);
+            if (rc) return rc;
+            op_add(c, outer, inner, outer, B, 2);
+        }
+    }
+    rt_d2d(state, outer, B * ctw * 8, w.stream);
+    return HHE_OK;
+}
+
 // PASTA_SEAL::diagonal (pasta_3_seal.cpp:370-413) for affine layer `layer`, state in ws_ct[0].
 // The 128 products are accumulated in the NTT domain and inverse-transformed once, which
 // yields the same words as SEAL's multiply_plain + add_inplace chain.
@@ -477,7 +550,7 @@ extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, si
 
 // one chunk of the batch on the current lane (c->w): the schedule of PASTA_SEAL::decomposition (pasta_3_seal.cpp:123-170)
 static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d_diag, const u64 *const *d_rc,
-                             const u64 *cw_padded_host, u64 *out, size_t B)
+                             const u64 *cw_padded_host, u64 *out, size_t B, bool bsgs)
 {
     const size_t n = c->n;
     const int L = c->L;
@@ -488,7 +561,7 @@ static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d
     // state <- enc_ssk[0] for every item (pasta_3_seal.cpp:126)
     op_elt(c, ELT_BCAST, nullptr, enc_key, state, B * 2 * L, 0, L, 2 * L);
     for (int r = 0; r <= PASTA_R && !rc; ++r) {
-        if ((rc = fused ? matmul_diagonal_fused(c, r, d_diag, B) : matmul_diagonal(c, r, d_diag, B))) break;
+        if ((rc = bsgs ? matmul_bsgs(c, r, d_diag, B) : fused ? matmul_diagonal_fused(c, r, d_diag, B) : matmul_diagonal(c, r, d_diag, B))) break;
         // add_rc (:205-211)
         op_add_plain(c, state, nullptr, d_rc, (size_t)r * n, false, false, false, state, B);
         // mix (:417-423)
@@ -523,13 +596,15 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
                                       const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
 {
     if (!c || !enc_key || !cw || !ncw || !block_index || !out || B == 0) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: null argument or empty batch");
-    if (use_bsgs) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: babystep-giantstep variant not built yet");
     const size_t n = c->n, half = n / 2;
     // pasta_3_seal.cpp:376-377
     if ((size_t)PASTA_T * 2 != n && (size_t)PASTA_T * 4 > n) return fail(HHE_ERR_TOO_FEW_SLOTS, "too little slots for matmul implementation!");
     if (!c->d_rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
     for (int step : {-1, half != PASTA_T ? PASTA_T : -1, 0})
         if (!c->d_gk.count(galois_elt_from_step(c, step))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    if (use_bsgs)  // add_gk_indices (:196-200): -k*BSGS_N1, k = 1..7
+        for (int k = 1; k < 8; ++k)
+            if (!c->d_gk.count(galois_elt_from_step(c, -16 * k))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     Lane &main = c->lanes[0];
     c->w = &main;
     int rc;
@@ -541,7 +616,8 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
         if (ncw[b] > PASTA_T) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: more than 128 words in a block");
         BlockTables *bt = nullptr;
         if ((rc = ensure_block(c, block_index[b], &bt))) return rc;
-        ptrs[b] = c->matmul_mode == 1 ? bt->pdiag : bt->diag;
+        if (use_bsgs && (rc = ensure_bsgs_tables(c, block_index[b], bt))) return rc;
+        ptrs[b] = use_bsgs ? bt->bsgs : c->matmul_mode == 1 ? bt->pdiag : bt->diag;
         ptrs[B + b] = bt->rc;
         memcpy(&cwp[b * PASTA_T], cw + b * PASTA_T, ncw[b] * 8);
     }
@@ -551,7 +627,7 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
 
     const int ns = c->nstreams;
     if (ns == 0) {
-        if (!(rc = lane_reserve(c, main, B))) rc = transcipher_chunk(c, enc_key, d_ptrs, d_ptrs + B, cwp.data(), out, B);
+        if (!(rc = lane_reserve(c, main, B))) rc = transcipher_chunk(c, enc_key, d_ptrs, d_ptrs + B, cwp.data(), out, B, use_bsgs != 0);
     } else {
         // independent chunks round-robin over the internal streams: a chunk's working set stays cache resident and
         // one stream's bandwidth-bound kernels overlap the other's issue-bound transforms
@@ -564,7 +640,7 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
             for (size_t b0 = 0; b0 < B && !rc; b0 += per, ++idx) {
                 const size_t bc = std::min(per, B - b0);
                 c->w = &c->lanes[1 + idx % ns];
-                rc = transcipher_chunk(c, enc_key, d_ptrs + b0, d_ptrs + B + b0, &cwp[b0 * PASTA_T], out + b0 * c->ct_words(), bc);
+                rc = transcipher_chunk(c, enc_key, d_ptrs + b0, d_ptrs + B + b0, &cwp[b0 * PASTA_T], out + b0 * c->ct_words(), bc, use_bsgs != 0);
             }
             for (int s = 1; s <= ns; ++s) {
                 rt_event_record(c->lanes[s].ev_done, c->lanes[s].stream);

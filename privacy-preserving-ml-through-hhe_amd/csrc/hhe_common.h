@@ -170,6 +170,13 @@ struct DiagArgs {  // PASTA_SEAL::diagonal preparation (pasta_3_seal.cpp:390-401
     int logn;
 };
 
+struct BsgsDiagArgs {  // PASTA_SEAL::babystep_giantstep diagonal preparation (pasta_3_seal.cpp:280-328) into slot order
+    const u64 *mats;   // [4][2][128][128]
+    u64 *out;          // [4*128][N]
+    const u32 *slot_map;
+    int logn, n1;      // n1 = BSGS_N1 (16)
+};
+
 struct BehzDev {  // SURVEY A.7 constants
     int L;
     u64 inv_punct_q[HHE_MAXL], inv_punct_q_s[HHE_MAXL];

@@ -296,6 +296,7 @@ static void free_lane(Lane &ln)
 {
     rt_free(ln.ws_T); rt_free(ln.ws_S); rt_free(ln.ws_d); rt_free(ln.ws_ct3); rt_free(ln.ws_plain); rt_free(ln.ws_vals);
     for (auto &p : ln.ws_ct) { rt_free(p); p = nullptr; }
+    rt_free(ln.ws_rot); ln.ws_rot = nullptr; ln.rot_cap = 0;
     rt_free(ln.bz_aq); rt_free(ln.bz_bq); rt_free(ln.bz_ab); rt_free(ln.bz_bb); rt_free(ln.bz_dq); rt_free(ln.bz_db);
     ln.ws_T = ln.ws_S = ln.ws_d = ln.ws_ct3 = ln.ws_plain = ln.ws_vals = nullptr;
     ln.bz_aq = ln.bz_bq = ln.bz_ab = ln.bz_bb = ln.bz_dq = ln.bz_db = nullptr;

@@ -30,6 +30,8 @@ struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `c
     u64 *bz_ab = nullptr, *bz_bb = nullptr;  // [B][2][L+1][N]
     u64 *bz_dq = nullptr;    // [B][3][L][N]
     u64 *bz_db = nullptr;    // [B][3][L+1][N]
+    u64 *ws_rot = nullptr;   // [B][16][2][L][N] babystep rotations (allocated on first BSGS use)
+    size_t rot_cap = 0;
 };
 
 struct hhe_ctx {

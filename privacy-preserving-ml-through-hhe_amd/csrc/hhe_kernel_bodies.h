@@ -441,6 +441,25 @@ HD void diag_body(const DiagArgs &a, size_t gid)
     a.out[((size_t)layer * PASTA_T + i) * n + a.slot_map[slot]] = v;
 }
 
+// babystep-giantstep diagonals (pasta_3_seal.cpp:280-328): diagonal i is rotated left by k*N1 (k = i / N1) and, when
+// the row is longer than 128 slots, its last k*N1 entries move to the end of the half row so that the later
+// rotate_rows(-k*N1) of the inner sum brings them back.  gid over [4 layers][128 diag][2 halves][128 j']
+HD void bsgs_diag_body(const BsgsDiagArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn, half = n >> 1;
+    const int jp = (int)(gid & 127);
+    const int h = (int)((gid >> 7) & 1);
+    const int i = (int)((gid >> 8) & 127);
+    const int layer = (int)(gid >> 15);
+    if (layer >= PASTA_R + 1) return;
+    const int shift = (i / a.n1) * a.n1;
+    const int j = (jp + shift) & 127;
+    const u64 v = a.mats[(((size_t)layer * 2 + h) * PASTA_T + j) * PASTA_T + ((j + PASTA_T - i) & 127)];
+    size_t pos = (size_t)jp;
+    if (half != PASTA_T && jp >= PASTA_T - shift) pos = half - PASTA_T + jp;
+    a.out[((size_t)layer * PASTA_T + i) * n + a.slot_map[pos + (h ? half : 0)]] = v;
+}
+
 // ------------------------------------------------------------------ BEHZ
 // fastbconv_m_tilde + sm_mrq (seal/util/rns.h:213-219): gid over [P][N]
 HD void behz_extend_body(const BehzExtendArgs &a, size_t gid)

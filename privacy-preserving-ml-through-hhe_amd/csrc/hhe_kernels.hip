@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(ELT_THREADS) ks_finish_kernel(KsFinishArgs a) 
 __global__ void __launch_bounds__(ELT_THREADS) add_plain_kernel(AddPlainArgs a) { add_plain_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) encode_scatter_kernel(EncodeArgs a) { encode_scatter_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) diag_kernel(DiagArgs a) { diag_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) bsgs_diag_kernel(BsgsDiagArgs a) { bsgs_diag_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) behz_extend_kernel(BehzExtendArgs a) { behz_extend_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) tensor_kernel(TensorArgs a) { tensor_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) behz_floor_kernel(BehzFloorArgs a) { behz_floor_body(a, GID); }
@@ -158,6 +159,7 @@ void k_encode_scatter(const EncodeArgs &a, rt_stream s)
     LAUNCH1D(encode_scatter_kernel, (size_t)a.B * a.count * (a.second_off >= 0 ? 2 : 1), s, a);
 }
 void k_diag(const DiagArgs &a, rt_stream s) { LAUNCH1D(diag_kernel, (size_t)(PASTA_R + 1) * PASTA_T * 2 * PASTA_T, s, a); }
+void k_bsgs_diag(const BsgsDiagArgs &a, rt_stream s) { LAUNCH1D(bsgs_diag_kernel, (size_t)(PASTA_R + 1) * PASTA_T * 2 * PASTA_T, s, a); }
 void k_behz_extend(const BehzExtendArgs &a, rt_stream s) { LAUNCH1D(behz_extend_kernel, (size_t)a.P << a.logn, s, a); }
 void k_tensor(const TensorArgs &a, rt_stream s) { LAUNCH1D(tensor_kernel, ((size_t)a.B * a.limbs) << a.logn, s, a); }
 void k_behz_floor(const BehzFloorArgs &a, rt_stream s) { LAUNCH1D(behz_floor_kernel, (size_t)a.P << a.logn, s, a); }

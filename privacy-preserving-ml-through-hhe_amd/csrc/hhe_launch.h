@@ -34,6 +34,7 @@ void k_ks_finish(const KsFinishArgs &a, rt_stream s);
 void k_add_plain(const AddPlainArgs &a, rt_stream s);
 void k_encode_scatter(const EncodeArgs &a, rt_stream s);
 void k_diag(const DiagArgs &a, rt_stream s);
+void k_bsgs_diag(const BsgsDiagArgs &a, rt_stream s);
 void k_behz_extend(const BehzExtendArgs &a, rt_stream s);
 void k_tensor(const TensorArgs &a, rt_stream s);
 void k_behz_floor(const BehzFloorArgs &a, rt_stream s);

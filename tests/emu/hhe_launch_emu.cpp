@@ -98,6 +98,7 @@ void k_ks_finish(const KsFinishArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L
 void k_add_plain(const AddPlainArgs &a, rt_stream) { LOOP((size_t)a.B << a.logn, add_plain_body(a, (size_t)g)); }
 void k_encode_scatter(const EncodeArgs &a, rt_stream) { LOOP((size_t)a.B * a.count * (a.second_off >= 0 ? 2 : 1), encode_scatter_body(a, (size_t)g)); }
 void k_diag(const DiagArgs &a, rt_stream) { LOOP((size_t)(PASTA_R + 1) * PASTA_T * 2 * PASTA_T, diag_body(a, (size_t)g)); }
+void k_bsgs_diag(const BsgsDiagArgs &a, rt_stream) { LOOP((size_t)(PASTA_R + 1) * PASTA_T * 2 * PASTA_T, bsgs_diag_body(a, (size_t)g)); }
 void k_behz_extend(const BehzExtendArgs &a, rt_stream) { LOOP((size_t)a.P << a.logn, behz_extend_body(a, (size_t)g)); }
 void k_tensor(const TensorArgs &a, rt_stream) { LOOP(((size_t)a.B * a.limbs) << a.logn, tensor_body(a, (size_t)g)); }
 void k_behz_floor(const BehzFloorArgs &a, rt_stream) { LOOP((size_t)a.P << a.logn, behz_floor_body(a, (size_t)g)); }

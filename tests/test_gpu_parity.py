@@ -197,3 +197,17 @@ def test_config5_n65536_six_primes_rotation_chain_and_multiply(orc, api, lib, me
     out = mem.empty((B,) + O.ct_shape)
     X.relinearize(o3, out, B)
     assert (mem.to_host(out)[0] == O.relinearize(mem.to_host(o3)[0], S.rk)).all()
+
+
+def test_babystep_giantstep_variant(orc, api, lib, mem):
+    S = Setup(orc, 10, [50] * 9, extra_steps=[-16 * k for k in range(1, 8)])
+    X = api.Context(S.logn, S.q, S.t, lib=lib)
+    S.load_keys(X)
+    pt = np.array([(13 * i + 2) % 256 for i in range(140)], dtype=np.uint64)
+    cw, ncw = S.sym_blocks(orc, pt)
+    out = mem.empty((2,) + S.O.ct_shape)
+    X.transcipher(mem.to_dev(S.enc_key), cw, ncw, [0, 1], out, use_bsgs=True)
+    res = mem.to_host(out)
+    for b in range(2):
+        assert (res[b] == S.O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b, use_bsgs=True)).all()
+        assert (S.O.decode(S.O.decrypt(S.sk, res[b]))[:ncw[b]] == pt[b * 128:b * 128 + ncw[b]]).all()

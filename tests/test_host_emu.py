@@ -127,3 +127,28 @@ def test_mixed_prime_sizes_force_digit_reduction(orc, api, emu_lib, mem):
     X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
     S.load_keys(X)
     pc.check_ops(X, S, mem, B=2, seed=11)
+
+
+def test_babystep_giantstep_variant_bit_exact(orc, api, emu_lib, mem):
+    """PASTA_SEAL::babystep_giantstep (pasta_3_seal.cpp:267-366; activate_bsgs) -- different ciphertext words than the
+    diagonal method, same plaintext; compared with the oracle's restatement and decrypted."""
+    S = Setup(orc, 10, [50] * 9, extra_steps=[-16 * k for k in range(1, 8)])
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    pt = np.array([(13 * i + 2) % 256 for i in range(140)], dtype=np.uint64)
+    cw, ncw = S.sym_blocks(orc, pt)
+    out = mem.empty((2,) + S.O.ct_shape)
+    X.transcipher(mem.to_dev(S.enc_key), cw, ncw, [0, 1], out, use_bsgs=True)
+    res = mem.to_host(out)
+    for b in range(2):
+        ref = S.O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b, use_bsgs=True)
+        assert (res[b] == ref).all()
+        assert (S.O.decode(S.O.decrypt(S.sk, res[b]))[:ncw[b]] == pt[b * 128:b * 128 + ncw[b]]).all()
+    plain = S.O.transcipher_block(S.enc_key, S.rk, S.gk, cw[0], 0, use_bsgs=False)
+    assert not (res[0] == plain).all()  # a different (reference-defined) ciphertext
+    Y = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    Y.set_relin_key(S.rk)
+    for i, e in enumerate(S.gk.elts[:3]):
+        Y.set_galois_key(int(e), S.gk.keys[i])
+    with pytest.raises(api.HheError):
+        Y.transcipher(mem.to_dev(S.enc_key), cw, ncw, [0, 1], out, use_bsgs=True)  # giant-step keys missing
