@@ -57,7 +57,9 @@ uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i);
 
 /* ---- keys: the by-value seal::RelinKeys / seal::GaloisKeys members of SEALZpCipher
  *      (src/pasta/SEAL_Cipher.h:28-31; ctor SEAL_Cipher.cpp:9-36).  Uploaded once, cached in HBM. ---- */
-int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk_hptr);
+int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk_hptr); /* slot 0: the key PASTA_SEAL was constructed with */
+/* further RelinKeys objects (e.g. the CSP's own csp_rk used at CSP.cpp:306); slot < 4 */
+int hhe_set_relin_key_slot(hhe_ctx *c, int slot, const uint64_t *ksk_hptr);
 int hhe_set_galois_key(hhe_ctx *c, uint32_t galois_elt, const uint64_t *ksk_hptr);
 int hhe_has_galois_key(const hhe_ctx *c, uint32_t galois_elt);
 
@@ -113,9 +115,13 @@ int hhe_flatten(hhe_ctx *c, const uint64_t *blocks_dptr, size_t nblocks, uint64_
 /* FC row: sealhelper::packed_enc_multiply + Evaluator::relinearize_inplace + sealhelper::encrypted_vec_sum
  * (src/util/sealhelper.cpp:268-274, src/examples/CSP/CSP.cpp:306, sealhelper.cpp:379-392).
  * vi [B][2][L][N]; w: weight-row ciphertexts [W][2][L][N]; item i uses w[i % W]. out [B][2][L][N];
- * the neuron's value is slot n_inputs-1 of the decryption. */
-int hhe_fc_row(hhe_ctx *c, const uint64_t *vi_dptr, const uint64_t *w_dptr, size_t W, size_t n_inputs,
-               uint64_t *out_dptr, size_t B);
+ * the neuron's value is slot n_inputs-1 of the decryption.  relin_slot selects the RelinKeys object;
+ * default_galois_only != 0 makes rotate_rows see only the power-of-two Galois elements, i.e. behave as if called
+ * with a GaloisKeys made by create_galois_keys() without arguments (what the CSP passes, CSP.cpp:312-316), even when
+ * the context also holds flatten / PASTA keys.  The n-1 NAF rotation chains share prefixes and are evaluated as a
+ * trie (identical ciphertext words, ~2.7x fewer key switches for n = 784). */
+int hhe_fc_row(hhe_ctx *c, const uint64_t *vi_dptr, const uint64_t *w_dptr, size_t W, size_t n_inputs, int relin_slot,
+               int default_galois_only, uint64_t *out_dptr, size_t B);
 
 /* PASTA-3 public randomness for one block as the kernels consume it (host; src/pasta/pasta_3_plain.cpp:56-119,286-295):
  * mats [4][2][128][128], rcs [4][2][128] */

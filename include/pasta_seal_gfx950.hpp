@@ -225,7 +225,7 @@ inline void fc_row(pasta::HheContext &ctx, const pasta::Ciphertext &vi, const pa
     hhe_ctx *h = ctx.handle();
     pasta::detail::check(hhe_copy_h2d(h, a.p, vi.words.data(), w * 8));
     pasta::detail::check(hhe_copy_h2d(h, b.p, w_row.words.data(), w * 8));
-    pasta::detail::check(hhe_fc_row(h, a.u64(), b.u64(), 1, vec_size, o.u64(), 1));
+    pasta::detail::check(hhe_fc_row(h, a.u64(), b.u64(), 1, vec_size, 0, 1, o.u64(), 1));
     pasta::detail::check(hhe_ctx_sync(h));
     destination.words.resize(w);
     destination.size = 2;

@@ -27,7 +27,7 @@ ERR_INVALID, ERR_NO_GALOIS_KEY, ERR_TOO_FEW_SLOTS, ERR_DEVICE, ERR_NO_RELIN_KEY 
 
 _SYMBOLS = [
     "hhe_last_error", "hhe_backend", "hhe_ctx_create", "hhe_ctx_destroy", "hhe_ctx_set_stream",
-    "hhe_ctx_reserve", "hhe_ctx_sync", "hhe_ctx_query", "hhe_set_relin_key", "hhe_set_galois_key",
+    "hhe_ctx_reserve", "hhe_ctx_sync", "hhe_ctx_query", "hhe_set_relin_key", "hhe_set_relin_key_slot", "hhe_set_galois_key",
     "hhe_has_galois_key", "hhe_malloc", "hhe_free", "hhe_copy_h2d", "hhe_copy_d2h", "hhe_ntt",
     "hhe_encode", "hhe_add", "hhe_negate", "hhe_add_plain", "hhe_multiply_plain", "hhe_apply_galois",
     "hhe_rotate_rows", "hhe_rotate_columns", "hhe_multiply", "hhe_relinearize",
@@ -193,8 +193,13 @@ class Context:
     def flatten(self, blocks, nblocks, out, S):
         self._chk(self.lib.hhe_flatten(self.h, _ptr(blocks), C.c_size_t(nblocks), _ptr(out), C.c_size_t(S)))
 
-    def fc_row(self, vi, w, W, n_inputs, out, B):
-        self._chk(self.lib.hhe_fc_row(self.h, _ptr(vi), _ptr(w), C.c_size_t(W), C.c_size_t(n_inputs), _ptr(out), C.c_size_t(B)))
+    def set_relin_key_slot(self, slot, ksk):
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        self._chk(self.lib.hhe_set_relin_key_slot(self.h, C.c_int(slot), _ptr(ksk)))
+
+    def fc_row(self, vi, w, W, n_inputs, out, B, relin_slot=0, default_galois_only=True):
+        self._chk(self.lib.hhe_fc_row(self.h, _ptr(vi), _ptr(w), C.c_size_t(W), C.c_size_t(n_inputs), C.c_int(relin_slot),
+                                      C.c_int(int(default_galois_only)), _ptr(out), C.c_size_t(B)))
 
 
 def block_randomness(t, block_index, lib=None):

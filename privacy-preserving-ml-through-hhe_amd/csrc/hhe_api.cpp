@@ -692,20 +692,89 @@ extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, u
     return HHE_OK;
 }
 
-extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, uint64_t *out, size_t B)
+// sealhelper::encrypted_vec_sum (sealhelper.cpp:379-392) adds rotate_rows(prod, -i) for i = 1..n-1, each rotation
+// going through SEAL's NAF decomposition (evaluator.h:955-1060).  The NAF term sequences of different i
+// share prefixes, and every key switch is a deterministic function of its input, so the rotations form a trie whose
+// nodes are computed once: 2875 key switches become 1054 for n = 784 with bit-identical ciphertexts
+// (modular addition is commutative, so the order of the final additions is free).
+namespace {
+struct NafNode {
+    int term = 0;
+    int mult = 0;                 // how many i end exactly here
+    std::vector<int> kids;
+};
+int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out, size_t B)
 {
-    if (!c || !vi || !w || !out || W == 0 || n_inputs == 0 || n_inputs > c->n / 2) return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
+    const size_t ctw = c->ct_words();
+    for (int kid : trie[node].kids) {
+        u64 *cur = bufs + (size_t)depth * B * ctw;
+        const u32 elt = galois_elt_from_step(c, trie[kid].term);
+        int rc = op_apply_galois(c, parent, elt, cur, B);
+        if (rc) return rc;
+        for (int m = 0; m < trie[kid].mult; ++m) op_add(c, out, cur, out, B, 2);
+        if ((rc = fc_dfs(c, trie, kid, depth + 1, cur, bufs, out, B))) return rc;
+    }
+    return HHE_OK;
+}
+}  // namespace
+
+extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
+                          int default_galois_only, uint64_t *out, size_t B)
+{
+    if (!c || !vi || !w || !out || W == 0 || n_inputs == 0 || n_inputs > c->n / 2 || relin_slot < 0 || relin_slot >= HHE_RELIN_SLOTS)
+        return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
+    if (!c->d_rk_slot[relin_slot]) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
     int rc = need(c, B);
     if (rc) return rc;
     const int L = c->L;
-    u64 *wb = c->w->ws_ct[0], *prod = c->w->ws_ct[1], *rot = c->w->ws_ct[2];
-    op_elt(c, ELT_BCAST, nullptr, w, wb, B * 2 * L, 0, L, (int)(W * 2 * L));
-    op_multiply(c, vi, wb, c->w->ws_ct3, B);                      // packed_enc_multiply
-    if ((rc = op_relinearize(c, c->w->ws_ct3, prod, B))) return rc;  // CSP.cpp:306
-    rt_d2d(out, prod, B * c->ct_words() * 8, c->w->stream);
-    for (size_t i = 1; i < n_inputs; ++i) {                    // encrypted_vec_sum (sealhelper.cpp:379-392)
-        if ((rc = op_rotate_rows(c, prod, -(int)i, rot, B))) return rc;
-        op_add(c, out, rot, out, B, 2);
+    const size_t ctw = c->ct_words();
+    // trie of NAF term sequences (terms equal to +-N/2 are skipped, evaluator.h rotate_internal)
+    std::vector<NafNode> trie(1);
+    int max_depth = 0;
+    for (size_t i = 1; i < n_inputs; ++i) {
+        const int step = -(int)i;
+        std::vector<int> terms;
+        const u32 direct = galois_elt_from_step(c, step);
+        const bool pow2 = (i & (i - 1)) == 0;
+        if (c->d_gk.count(direct) && (pow2 || !default_galois_only)) terms.push_back(step);  // has_key(elt): one key switch
+        else
+            for (int t : nt_naf(step))
+                if ((size_t)std::abs(t) != c->n / 2) terms.push_back(t);
+        if (terms.size() == 1 && !c->d_gk.count(galois_elt_from_step(c, terms[0]))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+        int node = 0;
+        for (int t : terms) {
+            if (!c->d_gk.count(galois_elt_from_step(c, t))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+            int next = -1;
+            for (int kid : trie[node].kids)
+                if (trie[kid].term == t) { next = kid; break; }
+            if (next < 0) {
+                next = (int)trie.size();
+                trie.push_back(NafNode());
+                trie[next].term = t;
+                trie[node].kids.push_back(next);
+            }
+            node = next;
+        }
+        trie[node].mult++;
+        max_depth = std::max(max_depth, (int)terms.size());
     }
-    return HHE_OK;
+    Lane &ln = *c->w;
+    if (ln.rot_cap < B || max_depth + 1 > 16) {
+        if (max_depth + 1 > 16) return fail(HHE_ERR_INVALID, "hhe_fc_row: NAF depth");
+        rt_sync(ln.stream);
+        rt_free(ln.ws_rot);
+        ln.ws_rot = (u64 *)rt_malloc(B * 16 * ctw * 8);
+        if (!ln.ws_rot) return dev_fail("hhe_fc_row workspace");
+        ln.rot_cap = B;
+    }
+    u64 *wb = ln.ws_ct[0], *prod = ln.ws_rot;  // depth-0 buffer holds the product
+    op_elt(c, ELT_BCAST, nullptr, w, wb, B * 2 * L, 0, L, (int)(W * 2 * L));
+    op_multiply(c, vi, wb, ln.ws_ct3, B);                                  // packed_enc_multiply
+    u64 *saved = c->d_rk;
+    c->d_rk = c->d_rk_slot[relin_slot];
+    rc = op_relinearize(c, ln.ws_ct3, prod, B);                            // CSP.cpp:306
+    c->d_rk = saved;
+    if (rc) return rc;
+    rt_d2d(out, prod, B * ctw * 8, ln.stream);
+    return fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, B);
 }

@@ -354,7 +354,7 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
         if (ln.own_stream) rt_stream_destroy(ln.stream);
     }
     rt_event_destroy(c->ev_fork);
-    rt_free(c->d_rk);
+    for (auto &p : c->d_rk_slot) rt_free(p);
     for (auto &kv : c->d_gk) rt_free(kv.second);
     rt_free(c->d_feistel_mask);
     rt_free(c->d_tables); rt_free(c->d_mods); rt_free(c->d_behz); rt_free(c->d_slot_map);
@@ -411,11 +411,14 @@ static int upload_key(hhe_ctx *c, u64 *&slot, const uint64_t *ksk)
     }
     return HHE_OK;
 }
-extern "C" int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk)
+extern "C" int hhe_set_relin_key_slot(hhe_ctx *c, int slot, const uint64_t *ksk)
 {
-    if (!c || !ksk) return HHE_ERR_INVALID;
-    return upload_key(c, c->d_rk, ksk);
+    if (!c || !ksk || slot < 0 || slot >= HHE_RELIN_SLOTS) return HHE_ERR_INVALID;
+    int rc = upload_key(c, c->d_rk_slot[slot], ksk);
+    if (slot == 0) c->d_rk = c->d_rk_slot[0];
+    return rc;
 }
+extern "C" int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk) { return hhe_set_relin_key_slot(c, 0, ksk); }
 extern "C" int hhe_set_galois_key(hhe_ctx *c, uint32_t elt, const uint64_t *ksk)
 {
     if (!c || !ksk || !(elt & 1) || elt >= 2 * c->n) { hhe_set_error("hhe_set_galois_key: invalid Galois element"); return HHE_ERR_INVALID; }

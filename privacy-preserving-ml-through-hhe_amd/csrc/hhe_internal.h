@@ -14,6 +14,7 @@ struct BlockTables {   // public per-(nonce, block index) data of one PASTA bloc
 };
 
 constexpr int HHE_MAX_STREAMS = 4;
+constexpr int HHE_RELIN_SLOTS = 4;
 struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `cap` ciphertexts)
     rt_stream stream = nullptr;
     void *ev_done = nullptr;
@@ -60,7 +61,8 @@ struct hhe_ctx {
     AddPlainArgs apl{};
 
     // keys
-    u64 *d_rk = nullptr;
+    u64 *d_rk = nullptr;                       // slot 0 (transciphering)
+    u64 *d_rk_slot[HHE_RELIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     std::map<u32, u64 *> d_gk;
 
     // PASTA public tables

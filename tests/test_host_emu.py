@@ -152,3 +152,32 @@ def test_babystep_giantstep_variant_bit_exact(orc, api, emu_lib, mem):
         Y.set_galois_key(int(e), S.gk.keys[i])
     with pytest.raises(api.HheError):
         Y.transcipher(mem.to_dev(S.enc_key), cw, ncw, [0, 1], out, use_bsgs=True)  # giant-step keys missing
+
+
+def test_fc_row_naf_trie_equals_sequential_rotations(orc, api, emu_lib, mem):
+    """hhe_fc_row evaluates the NAF rotation chains of encrypted_vec_sum as a prefix trie; the words must equal the
+    oracle's literal loop (sealhelper.cpp:379-392), including the ±N/2 skip rule (n > N/4) and key policies."""
+    S = Setup(orc, 10, [50] * 9, all_galois=True, extra_steps=(-300,))
+    O = S.O
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    X.set_relin_key_slot(1, S.rk)
+    rng = np.random.default_rng(4)
+    for n_in in (37, 400):
+        v = rng.integers(0, 4, n_in)
+        w = rng.integers(-8, 9, n_in)
+        vi = O.encrypt(S.pk, O.encode(v), 21)
+        wc = O.encrypt(S.pk, O.encode(w), 22)
+        out = mem.empty((1,) + O.ct_shape)
+        # the context also holds a key for step -300: with default_galois_only the call must ignore it ...
+        X.fc_row(mem.to_dev(vi[None]), mem.to_dev(wc[None]), 1, n_in, out, 1, relin_slot=1, default_galois_only=True)
+        dflt = orc.GaloisKeys(S.gk.elts[:-1], S.gk.keys[:-1])
+        ref, ks = O.fc_row(vi, wc, S.rk, dflt, n_in)
+        got = mem.to_host(out)[0]
+        assert (got == ref).all()
+        assert int(O.decode(O.decrypt(S.sk, got))[n_in - 1]) == int(np.dot(v, w)) % S.t
+        # ... and with the union policy it must use it, exactly like SEAL's has_key() shortcut
+        X.fc_row(mem.to_dev(vi[None]), mem.to_dev(wc[None]), 1, n_in, out, 1, relin_slot=0, default_galois_only=False)
+        ref2, _ = O.fc_row(vi, wc, S.rk, S.gk, n_in)
+        assert (mem.to_host(out)[0] == ref2).all()
+        assert n_in <= 300 or not (ref == ref2).all()
