@@ -548,6 +548,27 @@ extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, si
     return op_relinearize(c, a3, out, B);
 }
 
+// the fused matmul loop is launch bound on the host (1143 launches per affine layer): on the internal streams it is
+// captured once per (layer, batch) into a hipGraph and replayed; table pointers live in lane-owned device memory
+// whose contents, not address, change between calls
+static int run_matmul_fused(hhe_ctx *c, int layer, const u64 *const *d_diag, size_t B)
+{
+    Lane &ln = *c->w;
+    if (!c->use_graphs || !ln.own_stream || d_diag != ln.d_ptrs) return matmul_diagonal_fused(c, layer, d_diag, B);
+    const auto key = std::make_pair(layer, B);
+    auto it = ln.graphs.find(key);
+    if (it == ln.graphs.end()) {
+        if (rt_capture_begin(ln.stream)) return matmul_diagonal_fused(c, layer, d_diag, B);
+        int rc = matmul_diagonal_fused(c, layer, d_diag, B);
+        void *exec = rt_capture_end(ln.stream);
+        if (rc) { rt_graph_destroy(exec); return rc; }
+        if (!exec) { c->use_graphs = 0; return matmul_diagonal_fused(c, layer, d_diag, B); }
+        it = ln.graphs.emplace(key, exec).first;
+    }
+    if (rt_graph_launch(it->second, ln.stream)) return dev_fail("hipGraphLaunch");
+    return HHE_OK;
+}
+
 // one chunk of the batch on the current lane (c->w): the schedule of PASTA_SEAL::decomposition (pasta_3_seal.cpp:123-170)
 static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d_diag, const u64 *const *d_rc,
                              const u64 *cw_padded_host, u64 *out, size_t B, bool bsgs)
@@ -561,7 +582,7 @@ static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d
     // state <- enc_ssk[0] for every item (pasta_3_seal.cpp:126)
     op_elt(c, ELT_BCAST, nullptr, enc_key, state, B * 2 * L, 0, L, 2 * L);
     for (int r = 0; r <= PASTA_R && !rc; ++r) {
-        if ((rc = bsgs ? matmul_bsgs(c, r, d_diag, B) : fused ? matmul_diagonal_fused(c, r, d_diag, B) : matmul_diagonal(c, r, d_diag, B))) break;
+        if ((rc = bsgs ? matmul_bsgs(c, r, d_diag, B) : fused ? run_matmul_fused(c, r, d_diag, B) : matmul_diagonal(c, r, d_diag, B))) break;
         // add_rc (:205-211)
         op_add_plain(c, state, nullptr, d_rc, (size_t)r * n, false, false, false, state, B);
         // mix (:417-423)
@@ -621,36 +642,43 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
         ptrs[B + b] = bt->rc;
         memcpy(&cwp[b * PASTA_T], cw + b * PASTA_T, ncw[b] * 8);
     }
-    const u64 **d_ptrs = (const u64 **)rt_malloc(2 * B * sizeof(u64 *));
-    if (!d_ptrs) return dev_fail("hhe_pasta3_transcipher");
-    rt_h2d(d_ptrs, ptrs.data(), 2 * B * sizeof(u64 *), main.stream);
-
     const int ns = c->nstreams;
     if (ns == 0) {
-        if (!(rc = lane_reserve(c, main, B))) rc = transcipher_chunk(c, enc_key, d_ptrs, d_ptrs + B, cwp.data(), out, B, use_bsgs != 0);
+        if (!(rc = lane_reserve(c, main, B))) {
+            std::vector<const u64 *> lp(2 * main.ptr_cap, nullptr);
+            for (size_t b = 0; b < B; ++b) { lp[b] = ptrs[b]; lp[main.ptr_cap + b] = ptrs[B + b]; }
+            rt_h2d(main.d_ptrs, lp.data(), lp.size() * sizeof(u64 *), main.stream);
+            rc = transcipher_chunk(c, enc_key, main.d_ptrs, main.d_ptrs + main.ptr_cap, cwp.data(), out, B, use_bsgs != 0);
+        }
     } else {
         // independent chunks round-robin over the internal streams: a chunk's working set stays cache resident and
-        // one stream's bandwidth-bound kernels overlap the other's issue-bound transforms
+        // concurrent streams de-phase the load / butterfly / store phases of the transforms
         const size_t per = std::min(B, c->chunk);
         for (int s = 1; s <= ns && !rc; ++s) rc = lane_reserve(c, c->lanes[s], per);
         if (!rc) {
             rt_event_record(c->ev_fork, main.stream);
             for (int s = 1; s <= ns; ++s) rt_stream_wait_event(c->lanes[s].stream, c->ev_fork);
             size_t idx = 0;
+            std::vector<std::vector<const u64 *>> keep;  // host staging must outlive the asynchronous copies
             for (size_t b0 = 0; b0 < B && !rc; b0 += per, ++idx) {
                 const size_t bc = std::min(per, B - b0);
-                c->w = &c->lanes[1 + idx % ns];
-                rc = transcipher_chunk(c, enc_key, d_ptrs + b0, d_ptrs + B + b0, &cwp[b0 * PASTA_T], out + b0 * c->ct_words(), bc, use_bsgs != 0);
+                Lane &ln = c->lanes[1 + idx % ns];
+                c->w = &ln;
+                keep.emplace_back(2 * ln.ptr_cap, nullptr);
+                std::vector<const u64 *> &lp = keep.back();
+                for (size_t b = 0; b < bc; ++b) { lp[b] = ptrs[b0 + b]; lp[ln.ptr_cap + b] = ptrs[B + b0 + b]; }
+                rt_h2d(ln.d_ptrs, lp.data(), lp.size() * sizeof(u64 *), ln.stream);
+                rc = transcipher_chunk(c, enc_key, ln.d_ptrs, ln.d_ptrs + ln.ptr_cap, &cwp[b0 * PASTA_T], out + b0 * c->ct_words(), bc, use_bsgs != 0);
             }
             for (int s = 1; s <= ns; ++s) {
                 rt_event_record(c->lanes[s].ev_done, c->lanes[s].stream);
                 rt_stream_wait_event(main.stream, c->lanes[s].ev_done);
             }
+            if (rt_sync(main.stream) && !rc) rc = dev_fail("hhe_pasta3_transcipher");
         }
         c->w = &main;
     }
     if (rt_sync(main.stream) && !rc) rc = dev_fail("hhe_pasta3_transcipher");
-    rt_free(d_ptrs);
     return rc;
 }
 

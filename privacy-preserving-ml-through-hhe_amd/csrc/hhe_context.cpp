@@ -272,6 +272,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     c->ksc.half = kf.half;
     for (int j = 0; j < L; ++j) { c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j]; }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
+    if (const char *e = getenv("HHE_GRAPH")) c->use_graphs = atoi(e);
     if (const char *e = getenv("HHE_STREAMS")) c->nstreams = std::max(0, std::min(HHE_MAX_STREAMS, atoi(e)));
     if (const char *e = getenv("HHE_CHUNK")) c->chunk = (size_t)std::max(1, atoi(e));
     for (int s = 1; s <= c->nstreams; ++s) {
@@ -297,6 +298,9 @@ static void free_lane(Lane &ln)
     rt_free(ln.ws_T); rt_free(ln.ws_S); rt_free(ln.ws_d); rt_free(ln.ws_ct3); rt_free(ln.ws_plain); rt_free(ln.ws_vals);
     for (auto &p : ln.ws_ct) { rt_free(p); p = nullptr; }
     rt_free(ln.ws_rot); ln.ws_rot = nullptr; ln.rot_cap = 0;
+    for (auto &kv : ln.graphs) rt_graph_destroy(kv.second);
+    ln.graphs.clear();
+    rt_free((void *)ln.d_ptrs); ln.d_ptrs = nullptr; ln.ptr_cap = 0;
     rt_free(ln.bz_aq); rt_free(ln.bz_bq); rt_free(ln.bz_ab); rt_free(ln.bz_bb); rt_free(ln.bz_dq); rt_free(ln.bz_db);
     ln.ws_T = ln.ws_S = ln.ws_d = ln.ws_ct3 = ln.ws_plain = ln.ws_vals = nullptr;
     ln.bz_aq = ln.bz_bq = ln.bz_ab = ln.bz_bb = ln.bz_dq = ln.bz_db = nullptr;
@@ -330,6 +334,8 @@ int lane_reserve(hhe_ctx *c, Lane &ln, size_t B)
     ok &= !!(ln.bz_bb = alloc(B * 2 * (L + 1) * n));
     ok &= !!(ln.bz_dq = alloc(B * 3 * L * n));
     ok &= !!(ln.bz_db = alloc(B * 3 * (L + 1) * n));
+    ok &= !!(ln.d_ptrs = (const u64 **)rt_malloc(2 * B * sizeof(u64 *)));
+    ln.ptr_cap = B;
     if (!ok) { free_lane(ln); hhe_set_error(std::string("workspace allocation failed: ") + rt_last_error()); return HHE_ERR_DEVICE; }
     ln.cap = B;
     return HHE_OK;

@@ -31,6 +31,9 @@ struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `c
     u64 *bz_ab = nullptr, *bz_bb = nullptr;  // [B][2][L+1][N]
     u64 *bz_dq = nullptr;    // [B][3][L][N]
     u64 *bz_db = nullptr;    // [B][3][L+1][N]
+    const u64 **d_ptrs = nullptr;  // [2*cap] per-item public-table pointers (diag | rc), fixed address for graph replay
+    size_t ptr_cap = 0;
+    std::map<std::pair<int, size_t>, void *> graphs;  // (affine layer, batch) -> captured fused-matmul graph
     u64 *ws_rot = nullptr;   // [B][16][2][L][N] babystep rotations (allocated on first BSGS use)
     size_t rot_cap = 0;
 };
@@ -46,6 +49,7 @@ struct hhe_ctx {
     int nmod = 0;                  // K + (L+1) + 1
     int mod_t = 0;                 // index of the plain modulus
     int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
+    int use_graphs = 1;            // replay the fused matmul loop (1143 launches per layer) as a hipGraph on internal streams
     int matmul_mode = 1;           // 1: fused 20-transform pipeline (default), 0: op-by-op schedule
     KsConsts ksc{};
 

@@ -5,6 +5,7 @@
 // Bodies live in hhe_kernel_bodies.h; this file is the __global__ wrappers + launchers.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "hhe_kernel_bodies.h"
 #include "hhe_launch.h"
@@ -47,6 +48,22 @@ void *rt_event_create()
 void rt_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 int rt_event_record(void *ev, rt_stream s) { return rt_check(hipEventRecord((hipEvent_t)ev, (hipStream_t)s), "hipEventRecord"); }
 int rt_stream_wait_event(rt_stream s, void *ev) { return rt_check(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0), "hipStreamWaitEvent"); }
+int rt_capture_begin(rt_stream s)
+{
+    if (!s) return -1;  // the legacy default stream cannot be captured
+    return rt_check(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+}
+void *rt_capture_end(rt_stream s)
+{
+    hipGraph_t g = nullptr;
+    if (rt_check(hipStreamEndCapture((hipStream_t)s, &g), "hipStreamEndCapture") || !g) return nullptr;
+    hipGraphExec_t e = nullptr;
+    if (rt_check(hipGraphInstantiate(&e, g, nullptr, nullptr, 0), "hipGraphInstantiate")) e = nullptr;
+    (void)hipGraphDestroy(g);
+    return (void *)e;
+}
+int rt_graph_launch(void *exec, rt_stream s) { return rt_check(hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)s), "hipGraphLaunch"); }
+void rt_graph_destroy(void *exec) { if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec); }
 
 // ---------------------------------------------------------------- NTT
 template <int LOGM, bool STRIDED, bool INVERSE, int R>
@@ -101,11 +118,13 @@ static void launch_pass(NttArgs a, int logm, int other, hipStream_t st)
     if (logc > other) logc = other;
     a.logc = logc;
     dim3 grid(1u << (other - logc), (unsigned)a.count);
+    static int dyn_lds = -1;  // occupancy probe: extra dynamic LDS per workgroup (HHE_NTT_DYNLDS bytes)
+    if (dyn_lds < 0) { const char *e = getenv("HHE_NTT_DYNLDS"); dyn_lds = e ? atoi(e) : 0; }
     switch (logm) {
-    case 5: hipLaunchKernelGGL((ntt_pass_kernel<5, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), 0, st, a); break;
-    case 6: hipLaunchKernelGGL((ntt_pass_kernel<6, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), 0, st, a); break;
-    case 7: hipLaunchKernelGGL((ntt_pass_kernel<7, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((ntt_pass_kernel<8, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((ntt_pass_kernel<5, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
+    case 6: hipLaunchKernelGGL((ntt_pass_kernel<6, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
+    case 7: hipLaunchKernelGGL((ntt_pass_kernel<7, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
+    case 8: hipLaunchKernelGGL((ntt_pass_kernel<8, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
     default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", logm); break;
     }
 }

@@ -22,6 +22,12 @@ void *rt_event_create();
 void rt_event_destroy(void *ev);
 int rt_event_record(void *ev, rt_stream s);
 int rt_stream_wait_event(rt_stream s, void *ev);
+// stream capture into an executable graph (launch-bound inner loops); rt_capture_begin returns non-zero when the
+// backend cannot capture (then the caller enqueues directly)
+int rt_capture_begin(rt_stream s);
+void *rt_capture_end(rt_stream s);
+int rt_graph_launch(void *exec, rt_stream s);
+void rt_graph_destroy(void *exec);
 const char *rt_last_error();
 
 // kernels (all asynchronous on `s`)

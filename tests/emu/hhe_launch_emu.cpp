@@ -26,6 +26,10 @@ void *rt_event_create() { static int ev; return &ev; }
 void rt_event_destroy(void *) {}
 int rt_event_record(void *, rt_stream) { return 0; }
 int rt_stream_wait_event(rt_stream, void *) { return 0; }
+int rt_capture_begin(rt_stream) { return -1; }
+void *rt_capture_end(rt_stream) { return nullptr; }
+int rt_graph_launch(void *, rt_stream) { return -1; }
+void rt_graph_destroy(void *) {}
 
 template <int LOGM, bool STRIDED, bool INVERSE, int I, int S0>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
