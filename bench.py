@@ -133,7 +133,7 @@ def main():
         A = a_block_bytes(n, L, K)
         path_ms = dev_ms / args.steps
         traffic = None  # HBM-side bytes per launch of the path from rocprofv3 PMC passes (tools/pmc_traffic.py)
-        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_b256.json")
+        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_b256_final.json")
         if os.path.exists(tf):
             traffic = json.load(open(tf))["traffic_bytes_per_transciphering"] * B
         achieved = A * B / (path_ms * 1e-3) / 1e9
@@ -145,7 +145,7 @@ def main():
                                    f"batch-{B} independent 128-word PASTA-3 blocks per GPU, block counter 0",
                        "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256_final.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                          "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",
                          "algorithmic_bytes_per_unit": A, "units_per_launch": B, "launch_ms": path_ms,
                          "dominant_kernel": {"name": "ntt_pass_kernel (forward, both passes)", "polys": npoly,

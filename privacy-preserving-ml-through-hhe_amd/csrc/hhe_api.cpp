@@ -380,7 +380,12 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     const u32 ginv = (u32)nt_invmod(g, 2 * n);
     u64 *accp0 = c->w->ws_ct[1], *accp1 = c->w->ws_ct[1] + bln;
     u64 *c0n[2] = {c->w->ws_ct[2], c->w->ws_ct[2] + bln};
-    u64 *scr = c->w->ws_ct[3], *r = c->w->ws_ct[3] + bln;
+    u64 *scr = c->w->ws_ct[3], *r = c->w->ws_ct[3] + bln, *scr2 = c->w->ws_ct3;
+    // the c0 branch of step i (K5) is only needed by the c0 branch of step i+1: run it on the lane's side stream,
+    // beside the latency-bound c1 chain (K4b of this step, digit transforms of the next)
+    Lane &lane = *c->w;
+    const bool side = c->side_stream && lane.side != nullptr;
+    rt_stream s5 = side ? lane.side : lane.stream;
     rt_memset(c->w->ws_ct[1], 0, 2 * bln * 8, c->w->stream);
     {   // c0 -> NTT form ; d = galois(c1)
         NttArgs a = ntt_args(c, state, c0n[0], B * L, 0, L);
@@ -395,22 +400,32 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     int cur = 0;
     for (int i = 0; i < PASTA_T - 1; ++i) {
         const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
-        {   // digits: T[I][J] = NTT_J(d[I] mod q_J); diagonal digits feed the plain product
-            NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
-            a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
-            k_ntt(a, false, c->w->stream);
-        }
-        {
-            KsMacArgs m;
-            memset(&m, 0, sizeof(m));
-            m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
-            m.acc = accp1; m.mul_ptrs = d_pdiag_ptrs; m.mul_shift = shift;
-            k_ks_mac(m, c->w->stream);
+        {   // digits T[I][J] = NTT_J(d[I] mod q_J) and S_k[J] = sum_I T[I][J] * key[I][k][J]; the I = J digit also feeds
+            // the plain product.  Fused: the row pass keeps S in registers and never writes T.
+            const size_t sub = (c->digit_sub && c->digit_sub < B) ? c->digit_sub : B;
+            for (size_t o = 0; o < B; o += sub) {
+                const size_t bs = std::min(sub, B - o);
+                NttArgs a = ntt_args(c, c->w->ws_d + o * ln, c->w->ws_T, bs * L * K, 0, K);
+                a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+                KsMacArgs m;
+                memset(&m, 0, sizeof(m));
+                m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S + o * 2 * K * n; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)bs; m.L = L; m.K = K;
+                m.acc = accp1 + o * ln; m.mul_ptrs = d_pdiag_ptrs + o; m.mul_shift = shift;
+                if (side && i > 0 && o == 0) rt_stream_wait_event(lane.stream, lane.ev_k5[(i - 1) & 1]);  // S and r are about to be overwritten
+                if (c->mac_fuse) {
+                    k_ntt_first_pass(a, false, c->w->stream);
+                    k_digit_mac(a, m, c->w->stream);
+                } else {
+                    k_ntt(a, false, c->w->stream);
+                    k_ks_mac(m, c->w->stream);
+                }
+            }
         }
         {   // r_k = INTT(S_k[special]) + floor(q_sp/2)
             NttArgs a = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, r, B * 2, K - 1, 1);
             a.src_item_polys = 1; a.src_item_stride = (size_t)K * n; a.store_op = STORE_RSP;
             k_ntt(a, true, c->w->stream);
+            if (side) { rt_event_record(lane.ev_k4a[i & 1], lane.stream); rt_stream_wait_event(s5, lane.ev_k4a[i & 1]); }
         }
         {   // c1 of the next state, coefficient form, already passed through the Galois map for the next digits
             NttArgs a = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
@@ -419,14 +434,16 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             k_ntt(a, true, c->w->stream);
         }
         {   // c0 of the next state in NTT form + permuted-frame product of the current c0
-            NttArgs a = ntt_args(c, r, scr, B * L, 0, L);
+            NttArgs a = ntt_args(c, r, scr2, B * L, 0, L);
             a.src_item_polys = L; a.src_item_stride = 2 * n; a.src_div = L; a.load_op = LOAD_RNEG;
             a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.aux_r = c->w->ws_S; a.acc = accp0;
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g;
-            k_ntt(a, false, c->w->stream);
+            k_ntt(a, false, s5);
+            if (side) rt_event_record(lane.ev_k5[i & 1], s5);
         }
         cur ^= 1;
     }
+    if (side) rt_stream_wait_event(lane.stream, lane.ev_k5[(PASTA_T - 2) & 1]);
     const size_t shift = ((size_t)layer * PASTA_T + (PASTA_T - 1)) * ln;
     {   // last state: products only (a "virtual" rotation keeps the frame uniform)
         NttArgs a = ntt_args(c, c->w->ws_d, scr, B * L, 0, L);

@@ -273,12 +273,17 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     for (int j = 0; j < L; ++j) { c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j]; }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
     if (const char *e = getenv("HHE_GRAPH")) c->use_graphs = atoi(e);
+    if (const char *e = getenv("HHE_MACFUSE")) c->mac_fuse = atoi(e);
+    if (const char *e = getenv("HHE_SIDE")) c->side_stream = atoi(e);
+    if (const char *e = getenv("HHE_DIGIT_SUB")) c->digit_sub = (size_t)std::max(0, atoi(e));
     if (const char *e = getenv("HHE_STREAMS")) c->nstreams = std::max(0, std::min(HHE_MAX_STREAMS, atoi(e)));
     if (const char *e = getenv("HHE_CHUNK")) c->chunk = (size_t)std::max(1, atoi(e));
     for (int s = 1; s <= c->nstreams; ++s) {
         c->lanes[s].stream = rt_stream_create();
         c->lanes[s].own_stream = true;
         c->lanes[s].ev_done = rt_event_create();
+        c->lanes[s].side = rt_stream_create();
+        for (int e = 0; e < 2; ++e) { c->lanes[s].ev_k4a[e] = rt_event_create(); c->lanes[s].ev_k5[e] = rt_event_create(); }
     }
     c->ev_fork = rt_event_create();
     {   // a digit d_I < q_I may enter NTT_J unreduced when q_I < 4 q_J (butterfly inputs live in [0,4q))
@@ -308,8 +313,10 @@ static void free_lane(Lane &ln)
 }
 static void sync_all(hhe_ctx *c)
 {
-    for (auto &ln : c->lanes)
+    for (auto &ln : c->lanes) {
         if (&ln == &c->lanes[0] || ln.own_stream) rt_sync(ln.stream);
+        if (ln.side) rt_sync(ln.side);
+    }
 }
 
 int lane_reserve(hhe_ctx *c, Lane &ln, size_t B)
@@ -357,7 +364,8 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
     for (auto &ln : c->lanes) {
         free_lane(ln);
         rt_event_destroy(ln.ev_done);
-        if (ln.own_stream) rt_stream_destroy(ln.stream);
+        if (ln.own_stream) { rt_stream_destroy(ln.stream); rt_stream_destroy(ln.side); }
+        for (int e = 0; e < 2; ++e) { rt_event_destroy(ln.ev_k4a[e]); rt_event_destroy(ln.ev_k5[e]); }
     }
     rt_event_destroy(c->ev_fork);
     for (auto &p : c->d_rk_slot) rt_free(p);

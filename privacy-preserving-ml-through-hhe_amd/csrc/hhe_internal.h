@@ -18,6 +18,8 @@ constexpr int HHE_RELIN_SLOTS = 4;
 struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `cap` ciphertexts)
     rt_stream stream = nullptr;
     void *ev_done = nullptr;
+    rt_stream side = nullptr;      // second stream of the lane: the c0 branch of a rotation step runs beside the c1 branch
+    void *ev_k4a[2] = {nullptr, nullptr}, *ev_k5[2] = {nullptr, nullptr};
     bool own_stream = false;
     size_t cap = 0;
     u64 *ws_T = nullptr;     // [B][L][K][N]
@@ -50,6 +52,9 @@ struct hhe_ctx {
     int mod_t = 0;                 // index of the plain modulus
     int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
     int use_graphs = 1;            // replay the fused matmul loop (1143 launches per layer) as a hipGraph on internal streams
+    int side_stream = 0;           // overlap the off-critical-path c0 update (K5) with the next digit transforms
+    size_t digit_sub = 0;          // >0: run the digit transforms + inner product in sub-batches of this many items (T stays cache resident)
+    int mac_fuse = 0;              // fused digit-NTT row pass + key-switch inner product in the matmul loop
     int matmul_mode = 1;           // 1: fused 20-transform pipeline (default), 0: op-by-op schedule
     KsConsts ksc{};
 

@@ -128,6 +128,61 @@ static void launch_pass(NttArgs a, int logm, int other, hipStream_t st)
     default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", logm); break;
     }
 }
+template <int LOGM, int I, int S0>
+static __device__ __forceinline__ void dmac_rounds(const NttArgs &a, int bx, int by, u64 *lds)
+{
+    if constexpr (I < NttSchedV<1, LOGM>::R) {
+        constexpr int RHO = NttSchedV<1, LOGM>::rho(I);
+        ntt_body_round<LOGM, S0, RHO, false, false>(a, bx, by, threadIdx.x, lds);
+        __syncthreads();
+        dmac_rounds<LOGM, I + 1, S0 + RHO>(a, bx, by, lds);
+    }
+}
+template <int LOGM>
+__global__ void __launch_bounds__(NTT_THREADS) digit_mac_kernel(NttArgs a, KsMacArgs mk)
+{
+    __shared__ u64 lds[(1 << NttTile<1>::LOG) + 512];
+    u64 acc0[2 * DMAC_NPAIR], acc1[2 * DMAC_NPAIR];
+#pragma unroll
+    for (int k = 0; k < 2 * DMAC_NPAIR; k++) { acc0[k] = 0; acc1[k] = 0; }
+    const int b = blockIdx.y / a.K, J = blockIdx.y % a.K;
+    for (int I = 0; I < a.L; I++) {
+        const int by = (b * a.L + I) * a.K + J;
+        ntt_body_load<false, false>(a, blockIdx.x, by, threadIdx.x, lds);
+        __syncthreads();
+        dmac_rounds<LOGM, 0, 0>(a, blockIdx.x, by, lds);
+        digit_mac_phase(a, mk, blockIdx.x, by, I, threadIdx.x, lds, acc0, acc1);
+        __syncthreads();
+    }
+    digit_mac_store(a, mk, blockIdx.x, b * a.L * a.K + J, threadIdx.x, acc0, acc1);
+}
+void k_digit_mac(const NttArgs &a0, const KsMacArgs &mk, rt_stream s)
+{
+    NttArgs a = a0;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    a.logm = n2;
+    int logc = NttTile<1>::LOG - n2;
+    if (logc > n1) logc = n1;
+    a.logc = logc;
+    dim3 grid(1u << (n1 - logc), (unsigned)(mk.B * mk.K));
+    hipStream_t st = (hipStream_t)s;
+    switch (n2) {
+    case 5: hipLaunchKernelGGL((digit_mac_kernel<5>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
+    case 6: hipLaunchKernelGGL((digit_mac_kernel<6>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
+    case 7: hipLaunchKernelGGL((digit_mac_kernel<7>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
+    case 8: hipLaunchKernelGGL((digit_mac_kernel<8>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
+    default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", n2); break;
+    }
+}
+void k_ntt_first_pass(const NttArgs &a, bool inverse, rt_stream s)
+{
+    if (a.count <= 0) return;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    if (!inverse) launch_pass<true, false>(a, n1, n2, (hipStream_t)s);
+    else launch_pass<false, true>(a, n2, n1, (hipStream_t)s);
+}
 void k_ntt(const NttArgs &a, bool inverse, rt_stream s)
 {
     if (a.count <= 0) return;

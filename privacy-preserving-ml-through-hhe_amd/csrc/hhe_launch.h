@@ -32,6 +32,9 @@ const char *rt_last_error();
 
 // kernels (all asynchronous on `s`)
 void k_ntt(const NttArgs &a, bool inverse, rt_stream s);  // runs both passes; a.logm/logc ignored
+void k_ntt_first_pass(const NttArgs &a, bool inverse, rt_stream s);  // only the first pass (intermediate left in a.dst)
+// fused: row pass of the forward digit NTTs (after k_ntt_first_pass into a.dst = T) + key-switch inner product into m.S
+void k_digit_mac(const NttArgs &a, const KsMacArgs &m, rt_stream s);
 void k_elt(const EltArgs &a, int op, rt_stream s);
 void k_galois(const GaloisArgs &a, rt_stream s);
 void k_perm(const PermArgs &a, rt_stream s);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 #include "hhe_kernel_bodies.h"
 #include "hhe_launch.h"
@@ -80,6 +81,66 @@ static void launch_pass(NttArgs a, int logm, int other)
     case 8: pass_emu<8, STRIDED, INVERSE>(a, gx, gy); break;
     default: fprintf(stderr, "emu: unsupported pass size\n"); abort();
     }
+}
+template <int LOGM, int I, int S0>
+static void dmac_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds)
+{
+    if constexpr (I < NttSchedV<1, LOGM>::R) {
+        constexpr int RHO = NttSchedV<1, LOGM>::rho(I);
+        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, false, false>(a, bx, by, t, lds);
+        dmac_rounds_emu<LOGM, I + 1, S0 + RHO>(a, bx, by, lds);
+    }
+}
+template <int LOGM>
+static void digit_mac_emu(const NttArgs &a, const KsMacArgs &mk, int gx, int gy)
+{
+#pragma omp parallel
+    {
+        std::vector<u64> lds((1 << NttTile<1>::LOG) + 512);
+        std::vector<u64> acc0((size_t)NTT_THREADS * 2 * DMAC_NPAIR), acc1((size_t)NTT_THREADS * 2 * DMAC_NPAIR);
+#pragma omp for collapse(2)
+        for (int y = 0; y < gy; y++)
+            for (int bx = 0; bx < gx; bx++) {
+                std::fill(acc0.begin(), acc0.end(), 0);
+                std::fill(acc1.begin(), acc1.end(), 0);
+                const int b = y / a.K, J = y % a.K;
+                for (int I = 0; I < a.L; I++) {
+                    const int by = (b * a.L + I) * a.K + J;
+                    for (int t = 0; t < NTT_THREADS; t++) ntt_body_load<false, false>(a, bx, by, t, lds.data());
+                    dmac_rounds_emu<LOGM, 0, 0>(a, bx, by, lds.data());
+                    for (int t = 0; t < NTT_THREADS; t++)
+                        digit_mac_phase(a, mk, bx, by, I, t, lds.data(), &acc0[(size_t)t * 2 * DMAC_NPAIR], &acc1[(size_t)t * 2 * DMAC_NPAIR]);
+                }
+                for (int t = 0; t < NTT_THREADS; t++)
+                    digit_mac_store(a, mk, bx, b * a.L * a.K + J, t, &acc0[(size_t)t * 2 * DMAC_NPAIR], &acc1[(size_t)t * 2 * DMAC_NPAIR]);
+            }
+    }
+}
+void k_digit_mac(const NttArgs &a0, const KsMacArgs &mk, rt_stream)
+{
+    NttArgs a = a0;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    a.logm = n2;
+    int logc = NttTile<1>::LOG - n2;
+    if (logc > n1) logc = n1;
+    a.logc = logc;
+    const int gx = 1 << (n1 - logc), gy = mk.B * mk.K;
+    switch (n2) {
+    case 5: digit_mac_emu<5>(a, mk, gx, gy); break;
+    case 6: digit_mac_emu<6>(a, mk, gx, gy); break;
+    case 7: digit_mac_emu<7>(a, mk, gx, gy); break;
+    case 8: digit_mac_emu<8>(a, mk, gx, gy); break;
+    default: abort();
+    }
+}
+void k_ntt_first_pass(const NttArgs &a, bool inverse, rt_stream)
+{
+    if (a.count <= 0) return;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    if (!inverse) launch_pass<true, false>(a, n1, n2);
+    else launch_pass<false, true>(a, n2, n1);
 }
 void k_ntt(const NttArgs &a, bool inverse, rt_stream)
 {
