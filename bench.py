@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="transcipherings per rank per step")
+    ap.add_argument("--workload", default="config2", choices=["config2", "mnist"],
+                    help="config2: all blocks use counter 0 (BASELINE metric); mnist: 784-word samples = blocks 0..6 (last ragged)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-blocks-per-thread", type=int, default=1)
     args = ap.parse_args()
@@ -89,6 +91,9 @@ def main():
     cw = rng.integers(0, t, size=(B, 128), dtype=np.uint64)
     ncw = np.full(B, 128, np.uint32)
     bidx = np.zeros(B, np.uint64)
+    if args.workload == "mnist":  # BASELINE config 3 shape: samples of 784 words -> 7 blocks, sharded by sample
+        bidx = (np.arange(B) % 7).astype(np.uint64)
+        ncw = np.where(bidx == 6, 16, 128).astype(np.uint32)
     out = torch.zeros((B, 2, L, n), dtype=torch.int64, device=dev)
     X.reserve(B)
 
@@ -141,8 +146,9 @@ def main():
             "metric": "PASTA-3 transcipherings/sec (N=2^15, 4 RNS limbs)", "value": value, "unit": "transcipherings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: N=2^15, coeff_modulus 4x60-bit (L=3,K=4), t=65537, "
-                                   f"batch-{B} independent 128-word PASTA-3 blocks per GPU, block counter 0",
+            "config": {"workload": ("BASELINE config 2: N=2^15, coeff_modulus 4x60-bit (L=3,K=4), t=65537, "
+                                    f"batch-{B} independent 128-word PASTA-3 blocks per GPU, block counter 0") if args.workload == "config2" else
+                                   (f"MNIST-shaped: N=2^15, 4x60-bit, t=65537, batch-{B} blocks per GPU = 784-word samples x 7 block counters (last block 16 words)"),
                        "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256_final.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",

@@ -112,6 +112,12 @@ int hhe_mask(hhe_ctx *c, const uint64_t *ct_dptr, const uint64_t *mask_vals_hptr
              uint64_t *out_dptr, size_t B);
 /* SEALZpCipher::flatten (src/pasta/SEAL_Cipher.cpp:170-181): blocks [S][nblocks][2][L][N] -> out [S][2][L][N] */
 int hhe_flatten(hhe_ctx *c, const uint64_t *blocks_dptr, size_t nblocks, uint64_t *out_dptr, size_t S);
+/* BaseCSP::decompose (src/examples/CSP/CSP.cpp:235-283): S records of nwords symmetric-ciphertext words (host, [S][nwords])
+ * -> decomposition of every block + mask of the ragged last block (mask_last != 0: as hhe_pktnn_examples.cpp:620-626;
+ * the CSP's own loop at CSP.cpp:264-269 masks a copy, i.e. has no effect: pass 0 to reproduce that) + flatten.
+ * out [S][2][L][N] device.  Needs the PASTA keys plus Galois keys reaching steps -128*i (directly or through NAF). */
+int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key_dptr, const uint64_t *records_hptr, size_t S, size_t nwords,
+                  int mask_last, uint64_t *out_dptr);
 /* FC row: sealhelper::packed_enc_multiply + Evaluator::relinearize_inplace + sealhelper::encrypted_vec_sum
  * (src/util/sealhelper.cpp:268-274, src/examples/CSP/CSP.cpp:306, sealhelper.cpp:379-392).
  * vi [B][2][L][N]; w: weight-row ciphertexts [W][2][L][N]; item i uses w[i % W]. out [B][2][L][N];

@@ -31,7 +31,7 @@ _SYMBOLS = [
     "hhe_has_galois_key", "hhe_malloc", "hhe_free", "hhe_copy_h2d", "hhe_copy_d2h", "hhe_ntt",
     "hhe_encode", "hhe_add", "hhe_negate", "hhe_add_plain", "hhe_multiply_plain", "hhe_apply_galois",
     "hhe_rotate_rows", "hhe_rotate_columns", "hhe_multiply", "hhe_relinearize",
-    "hhe_pasta3_transcipher", "hhe_pasta3_clear_block_cache", "hhe_mask", "hhe_flatten", "hhe_fc_row",
+    "hhe_pasta3_transcipher", "hhe_pasta3_clear_block_cache", "hhe_mask", "hhe_flatten", "hhe_fc_row", "hhe_decompose",
     "hhe_pasta3_block_randomness",
 ]
 
@@ -192,6 +192,13 @@ class Context:
 
     def flatten(self, blocks, nblocks, out, S):
         self._chk(self.lib.hhe_flatten(self.h, _ptr(blocks), C.c_size_t(nblocks), _ptr(out), C.c_size_t(S)))
+
+    def decompose(self, enc_key, records, out, mask_last=True):
+        """records: host uint64 [S][nwords]; out device [S][2][L][N]"""
+        rec = np.ascontiguousarray(records, dtype=np.uint64)
+        S, nwords = rec.shape
+        self._chk(self.lib.hhe_decompose(self.h, _ptr(enc_key), _ptr(rec), C.c_size_t(S), C.c_size_t(nwords),
+                                         C.c_int(int(mask_last)), _ptr(out)))
 
     def set_relin_key_slot(self, slot, ksk):
         ksk = np.ascontiguousarray(ksk, dtype=np.uint64)

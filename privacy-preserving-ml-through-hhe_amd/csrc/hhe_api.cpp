@@ -737,6 +737,46 @@ extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, u
     return HHE_OK;
 }
 
+// BaseCSP::decompose (src/examples/CSP/CSP.cpp:235-283) / hhe_pktnn_1fc_inference (hhe_pktnn_examples.cpp:578-630) on device:
+// per record: decomposition of every 128-word block, mask of the ragged last block, flatten -- without leaving HBM.
+extern "C" int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *records, size_t S, size_t nwords,
+                             int mask_last, uint64_t *out)
+{
+    if (!c || !enc_key || !records || !out || S == 0 || nwords == 0) return fail(HHE_ERR_INVALID, "hhe_decompose: bad arguments");
+    const size_t nb = (nwords + PASTA_T - 1) / PASTA_T, rem = nwords % PASTA_T, ctw = c->ct_words();
+    if (nb * PASTA_T > c->n / 2) return fail(HHE_ERR_INVALID, "hhe_decompose: record does not fit one batching row");
+    std::vector<u64> cw(S * nb * PASTA_T, 0), bidx(S * nb);
+    std::vector<uint32_t> ncw(S * nb);
+    for (size_t s = 0; s < S; ++s)
+        for (size_t b = 0; b < nb; ++b) {
+            const size_t lo = b * PASTA_T, hi = std::min(lo + PASTA_T, nwords);
+            memcpy(&cw[(s * nb + b) * PASTA_T], records + s * nwords + lo, (hi - lo) * 8);
+            ncw[s * nb + b] = (uint32_t)(hi - lo);
+            bidx[s * nb + b] = b;
+        }
+    u64 *blocks = (u64 *)rt_malloc(S * nb * ctw * 8);
+    if (!blocks) return dev_fail("hhe_decompose");
+    int rc = hhe_pasta3_transcipher(c, enc_key, cw.data(), ncw.data(), bidx.data(), S * nb, 0, blocks);
+    if (!rc && mask_last && rem) {
+        // hhe_pktnn_examples.cpp:620-625: ones on the first `rem` slots (CSP.cpp:264-269 intends the same)
+        u64 *last = (u64 *)rt_malloc(S * ctw * 8);
+        if (!last) rc = dev_fail("hhe_decompose");
+        else {
+            rt_stream st = c->lanes[0].stream;
+            for (size_t s = 0; s < S; ++s) rt_d2d(last + s * ctw, blocks + (s * nb + nb - 1) * ctw, ctw * 8, st);
+            std::vector<u64> ones(rem, 1);
+            rc = hhe_mask(c, last, ones.data(), rem, last, S);
+            for (size_t s = 0; s < S && !rc; ++s) rt_d2d(blocks + (s * nb + nb - 1) * ctw, last + s * ctw, ctw * 8, st);
+            rt_sync(st);
+            rt_free(last);
+        }
+    }
+    if (!rc) rc = hhe_flatten(c, blocks, nb, out, S);
+    if (!rc && rt_sync(c->lanes[0].stream)) rc = dev_fail("hhe_decompose");
+    rt_free(blocks);
+    return rc;
+}
+
 // sealhelper::encrypted_vec_sum (sealhelper.cpp:379-392) adds rotate_rows(prod, -i) for i = 1..n-1, each rotation
 // going through SEAL's NAF decomposition (evaluator.h:955-1060).  The NAF term sequences of different i
 // share prefixes, and every key switch is a deterministic function of its input, so the rotations form a trie whose

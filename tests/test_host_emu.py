@@ -181,3 +181,27 @@ def test_fc_row_naf_trie_equals_sequential_rotations(orc, api, emu_lib, mem):
         ref2, _ = O.fc_row(vi, wc, S.rk, S.gk, n_in)
         assert (mem.to_host(out)[0] == ref2).all()
         assert n_in <= 300 or not (ref == ref2).all()
+
+
+def test_decompose_record_mask_flatten(orc, api, emu_lib, mem):
+    """BaseCSP::decompose on device: blocks -> mask(last) -> flatten for a batch of records, vs the oracle's op sequence"""
+    S = Setup(orc, 10, [50] * 9, extra_steps=(-128, -256))
+    O = S.O
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    nwords, nrec = 300, 2
+    recs, pts = [], []
+    for s in range(nrec):
+        pt = np.array([(7 * i + 3 + s) % 256 for i in range(nwords)], dtype=np.uint64)
+        pts.append(pt)
+        recs.append(orc.pasta_encrypt(S.t, S.key, pt))
+    out = mem.empty((nrec,) + O.ct_shape)
+    X.decompose(mem.to_dev(S.enc_key), np.stack(recs), out, mask_last=True)
+    res = mem.to_host(out)
+    for s in range(nrec):
+        cw, ncw = S.sym_blocks(orc, pts[s])
+        blocks = [O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b) for b in range(3)]
+        blocks[2] = O.mask(blocks[2], np.ones(44, np.uint64))
+        ref = O.flatten(np.stack(blocks), S.gk)
+        assert (res[s] == ref).all()
+        assert (O.decode(O.decrypt(S.sk, res[s]))[:nwords] == pts[s]).all()
