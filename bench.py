@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--workload", default="config2", choices=["config2", "mnist"],
                     help="config2: all blocks use counter 0 (BASELINE metric); mnist: 784-word samples = blocks 0..6 (last ragged)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-blocks-per-thread", type=int, default=1)
+    ap.add_argument("--cpu-blocks-per-thread", type=int, default=2)
     args = ap.parse_args()
 
     import torch
