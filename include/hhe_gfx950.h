@@ -45,6 +45,9 @@ const char *hhe_backend(void);
  *      prime list: q[K] = coeff_modulus (last = special key-switch prime), t = plain_modulus.
  *      Derives NTT tables, BatchEncoder map, BEHZ base exactly as SEAL 4.0.0 does. ---- */
 int hhe_ctx_create(int logn, int K, const uint64_t *q_hptr, uint64_t t, int device, hhe_ctx **out);
+/* the prime chain SEALZpCipher::create_context picks: CoeffModulus::BFVDefault(N) for N <= 32768 and the hard-coded
+ * 29-prime chain for N = 65536 (src/pasta/SEAL_Cipher.cpp:47-65).  *count: in = capacity, out = number of primes. */
+int hhe_bfv_default_coeff_modulus(size_t poly_modulus_degree, uint64_t *out_hptr, size_t *count);
 void hhe_ctx_destroy(hhe_ctx *c);
 /* run all work of this context on an existing HIP stream (hipStream_t); NULL = default stream */
 int hhe_ctx_set_stream(hhe_ctx *c, void *hip_stream);

@@ -107,6 +107,18 @@ public:
     virtual std::vector<Ciphertext> HE_decrypt(std::vector<uint64_t> &ciphertext, bool batch_encoder = false) = 0;
     virtual void add_gk_indices() = 0;
 
+    // SEALZpCipher::create_context (src/pasta/SEAL_Cipher.cpp:38-68)
+    static std::shared_ptr<HheContext> create_context(size_t mod_degree, uint64_t plain_mod, int seclevel = 128, int device = 0)
+    {
+        if (seclevel != 128) throw std::runtime_error("Security Level not supported");
+        uint64_t q[64];
+        size_t cnt = 64;
+        if (hhe_bfv_default_coeff_modulus(mod_degree, q, &cnt) != HHE_OK) throw std::invalid_argument(hhe_last_error());
+        int logn = 0;
+        while (((size_t)1 << logn) < mod_degree) logn++;
+        return std::make_shared<HheContext>(logn, std::vector<uint64_t>(q, q + cnt), plain_mod, device);
+    }
+
     void activate_bsgs(bool activate) { use_bsgs = activate; }
     void set_bsgs_params(uint64_t n1, uint64_t n2) { bsgs_n1 = n1; bsgs_n2 = n2; }
     void add_some_gk_indices(std::vector<int> &gk_ind) { for (int i : gk_ind) gk_indices.push_back(i); }

@@ -26,7 +26,7 @@ class HheError(RuntimeError):
 ERR_INVALID, ERR_NO_GALOIS_KEY, ERR_TOO_FEW_SLOTS, ERR_DEVICE, ERR_NO_RELIN_KEY = 1, 2, 3, 4, 5
 
 _SYMBOLS = [
-    "hhe_last_error", "hhe_backend", "hhe_ctx_create", "hhe_ctx_destroy", "hhe_ctx_set_stream",
+    "hhe_last_error", "hhe_backend", "hhe_ctx_create", "hhe_bfv_default_coeff_modulus", "hhe_ctx_destroy", "hhe_ctx_set_stream",
     "hhe_ctx_reserve", "hhe_ctx_sync", "hhe_ctx_query", "hhe_set_relin_key", "hhe_set_relin_key_slot", "hhe_set_galois_key",
     "hhe_has_galois_key", "hhe_malloc", "hhe_free", "hhe_copy_h2d", "hhe_copy_d2h", "hhe_ntt",
     "hhe_encode", "hhe_add", "hhe_negate", "hhe_add_plain", "hhe_multiply_plain", "hhe_apply_galois",
@@ -207,6 +207,16 @@ class Context:
     def fc_row(self, vi, w, W, n_inputs, out, B, relin_slot=0, default_galois_only=True):
         self._chk(self.lib.hhe_fc_row(self.h, _ptr(vi), _ptr(w), C.c_size_t(W), C.c_size_t(n_inputs), C.c_int(relin_slot),
                                       C.c_int(int(default_galois_only)), _ptr(out), C.c_size_t(B)))
+
+
+def bfv_default_coeff_modulus(n, lib=None):
+    lib = lib or load_library()
+    out = np.zeros(64, np.uint64)
+    cnt = C.c_size_t(64)
+    rc = lib.hhe_bfv_default_coeff_modulus(C.c_size_t(n), _ptr(out), C.byref(cnt))
+    if rc:
+        raise HheError(rc, lib.hhe_last_error().decode())
+    return [int(v) for v in out[:cnt.value]]
 
 
 def block_randomness(t, block_index, lib=None):

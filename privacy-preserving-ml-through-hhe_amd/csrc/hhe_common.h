@@ -13,7 +13,7 @@
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-constexpr int HHE_MAXL = 16;          // data-level RNS limbs supported
+constexpr int HHE_MAXL = 32;          // data-level RNS limbs supported (the reference's N=65536 chain has 29 primes)
 constexpr int HHE_MAXK = HHE_MAXL + 1;
 constexpr int PASTA_T = 128;          // pasta_3_plain.h:18,32
 constexpr int PASTA_R = 3;            // pasta_3_plain.h:33

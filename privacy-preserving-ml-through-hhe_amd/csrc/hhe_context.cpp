@@ -154,10 +154,48 @@ static void fill_mod(ModDev &md, u64 q, int logn, u64 t, bool with_tables, u64 *
     md.w = dev_tab; md.ws = dev_tab + n; md.iw = dev_tab + 2 * n; md.iws = dev_tab + 3 * n;
 }
 
+// CoeffModulus::BFVDefault(N) (seal/coeffmodulus via util/globals.cpp, SEAL 4.0.0) as used by
+// SEALZpCipher::create_context (src/pasta/SEAL_Cipher.cpp:62-65) and the hard-coded N = 65536 chain (:50-60).
+// N = 16384 is pinned by SURVEY A.10; every list is prime, = 1 mod 2N, and sums to the bit count of
+// seal/util/hestdparms.h:seal_he_std_parms_128_tc (tests/test_abi.py).
+extern "C" int hhe_bfv_default_coeff_modulus(size_t n, uint64_t *out, size_t *count)
+{
+    static const std::vector<u64> t1024 = {0x7e00001ULL}, t2048 = {0x3fffffff000001ULL},
+        t4096 = {0xffffee001ULL, 0xffffc4001ULL, 0x1ffffe0001ULL},
+        t8192 = {0x7fffffd8001ULL, 0x7fffffc8001ULL, 0xfffffffc001ULL, 0xffffff6c001ULL, 0xfffffebc001ULL},
+        t16384 = {0xfffffffd8001ULL, 0xfffffffa0001ULL, 0xfffffff00001ULL, 0x1fffffff68001ULL, 0x1fffffff50001ULL,
+                  0x1ffffffee8001ULL, 0x1ffffffea0001ULL, 0x1ffffffe88001ULL, 0x1ffffffe48001ULL},
+        t32768 = {0x7fffffffe90001ULL, 0x7fffffffbf0001ULL, 0x7fffffffbd0001ULL, 0x7fffffffba0001ULL, 0x7fffffffaa0001ULL,
+                  0x7fffffffa50001ULL, 0x7fffffff9f0001ULL, 0x7fffffff7e0001ULL, 0x7fffffff770001ULL, 0x7fffffff380001ULL,
+                  0x7fffffff330001ULL, 0x7fffffff2d0001ULL, 0x7fffffff170001ULL, 0x7fffffff150001ULL, 0x7ffffffef00001ULL,
+                  0xfffffffff70001ULL},
+        t65536 = {0xffffffffffc0001ULL, 0xfffffffff840001ULL, 0xfffffffff6a0001ULL, 0xfffffffff5a0001ULL, 0xfffffffff2a0001ULL,
+                  0xfffffffff240001ULL, 0xffffffffefe0001ULL, 0xffffffffeca0001ULL, 0xffffffffe9e0001ULL, 0xffffffffe7c0001ULL,
+                  0xffffffffe740001ULL, 0xffffffffe520001ULL, 0xffffffffe4c0001ULL, 0xffffffffe440001ULL, 0xffffffffe400001ULL,
+                  0xffffffffdda0001ULL, 0xffffffffdd20001ULL, 0xffffffffdbc0001ULL, 0xffffffffdb60001ULL, 0xffffffffd8a0001ULL,
+                  0xffffffffd840001ULL, 0xffffffffd6e0001ULL, 0xffffffffd680001ULL, 0xffffffffd2a0001ULL, 0xffffffffd000001ULL,
+                  0xffffffffcf00001ULL, 0xffffffffcea0001ULL, 0xffffffffcdc0001ULL, 0xffffffffcc40001ULL};
+    const std::vector<u64> *t = nullptr;
+    switch (n) {
+    case 1024: t = &t1024; break;
+    case 2048: t = &t2048; break;
+    case 4096: t = &t4096; break;
+    case 8192: t = &t8192; break;
+    case 16384: t = &t16384; break;
+    case 32768: t = &t32768; break;
+    case 65536: t = &t65536; break;
+    default: hhe_set_error("non-standard poly_modulus_degree"); return HHE_ERR_INVALID;
+    }
+    if (!count) return HHE_ERR_INVALID;
+    if (out && *count >= t->size()) memcpy(out, t->data(), t->size() * 8);
+    *count = t->size();
+    return HHE_OK;
+}
+
 extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, int device, hhe_ctx **out)
 {
     if (!out || !q || logn < 10 || logn > 16 || K < 2 || K > HHE_MAXK) {
-        hhe_set_error("hhe_ctx_create: invalid arguments (need 10 <= logn <= 16, 2 <= K <= 17)");
+        hhe_set_error("hhe_ctx_create: invalid arguments (need 10 <= logn <= 16, 2 <= K <= 33)");
         return HHE_ERR_INVALID;
     }
     const size_t n = (size_t)1 << logn;

@@ -47,3 +47,22 @@ def test_product_pasta_randomness_matches_reference_golden(product_lib):
         mats, rcs = api.block_randomness(c["t"], c["block"], lib=lib)
         assert hashlib.sha256(mats.tobytes()).hexdigest() == c["mats_sha256"]
         assert [int(v) for v in rcs[0].reshape(-1)] == c["rc_r0"]
+
+
+def test_bfv_default_chains(product_lib):
+    """SEALZpCipher::create_context's prime chains: N=16384 equals SURVEY A.10; all are NTT primes whose total bit count
+    is seal_he_std_parms_128_tc(N) from the reference's seal/util/hestdparms.h; N=65536 is SEAL_Cipher.cpp:50-60."""
+    api = importlib.import_module(PKG + ".api")
+    lib = api.load_library()
+    import oracle as orc
+    assert api.bfv_default_coeff_modulus(16384, lib) == [
+        281474976546817, 281474976317441, 281474975662081, 562949952798721, 562949952700417,
+        562949952274433, 562949951979521, 562949951881217, 562949951619073]
+    for n, bits in ((1024, 27), (2048, 54), (4096, 109), (8192, 218), (16384, 438), (32768, 881)):
+        ch = api.bfv_default_coeff_modulus(n, lib)
+        assert sum(p.bit_length() for p in ch) == bits
+        assert all(orc.lib().orc_is_prime(p) and (p - 1) % (2 * n) == 0 for p in ch)
+    big = api.bfv_default_coeff_modulus(65536, lib)
+    assert len(big) == 29 and big[0] == 0xffffffffffc0001 and big[-1] == 0xffffffffcc40001
+    with pytest.raises(api.HheError):
+        api.bfv_default_coeff_modulus(12345, lib)

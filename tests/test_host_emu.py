@@ -205,3 +205,19 @@ def test_decompose_record_mask_flatten(orc, api, emu_lib, mem):
         ref = O.flatten(np.stack(blocks), S.gk)
         assert (res[s] == ref).all()
         assert (O.decode(O.decrypt(S.sk, res[s]))[:nwords] == pts[s]).all()
+
+
+def test_reference_n65536_29_prime_context_is_accepted(orc, api, emu_lib, mem):
+    """the reference's hard-coded N=65536 parameter set (SEAL_Cipher.cpp:50-60: 29 primes, L=28): context tables and
+    a 28-limb ciphertext add / NTT round trip (the deep BEHZ / key-switch arrays are sized for it)"""
+    t = 8088322049
+    q = api.bfv_default_coeff_modulus(65536, emu_lib)
+    X = api.Context(16, q, t, lib=emu_lib)
+    assert X.L == 28
+    assert X.query("root", 0) == orc.minimal_primitive_root(1 << 17, q[0])
+    rng = np.random.default_rng(0)
+    a = np.stack([rng.integers(0, q[j], 1 << 16, dtype=np.uint64) for j in range(28)])
+    d = mem.to_dev(a)
+    X.ntt(d, 28, 0, 28, False)
+    X.ntt(d, 28, 0, 28, True)
+    assert (mem.to_host(d) == a).all()
