@@ -91,13 +91,11 @@ struct NttRounds {
     }
 };
 
-#if HHE_NTT_VARIANT == 0
-#define NTT_MIN_WAVES 1
-#else
-#define NTT_MIN_WAVES 2
+#ifndef NTT_WAVES_PER_SIMD
+#define NTT_WAVES_PER_SIMD (HHE_PASS_V == 0 ? 4 : 6)
 #endif
 template <int LOGM, bool STRIDED, bool INVERSE>
-__global__ void __launch_bounds__(NTT_THREADS, NTT_MIN_WAVES * 4) ntt_pass_kernel(NttArgs a)
+__global__ void __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) ntt_pass_kernel(NttArgs a)
 {
     __shared__ u64 lds[NTT_LDS_ELEMS];
     ntt_body_load<STRIDED, INVERSE>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);

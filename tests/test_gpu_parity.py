@@ -211,3 +211,21 @@ def test_babystep_giantstep_variant(orc, api, lib, mem):
     for b in range(2):
         assert (res[b] == S.O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b, use_bsgs=True)).all()
         assert (S.O.decode(S.O.decrypt(S.sk, res[b]))[:ncw[b]] == pt[b * 128:b * 128 + ncw[b]]).all()
+
+
+@pytest.mark.parametrize("knobs", [
+    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MACFUSE": "1"}, {"HHE_SIDE": "1"},
+    {"HHE_DIGIT_SUB": "1", "HHE_CHUNK": "4"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"}, {"HHE_GRAPH": "0"},
+])
+def test_execution_knobs_are_result_neutral(orc, api, lib, mem, small, monkeypatch, knobs):
+    pt = [(3 * i + 1) % 256 for i in range(300)]
+    cw, ncw = small.sym_blocks(orc, pt)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    X = api.Context(small.logn, small.q, small.t, lib=lib)
+    small.load_keys(X)
+    out = mem.empty((3,) + small.O.ct_shape)
+    X.transcipher(mem.to_dev(small.enc_key), cw, ncw, [0, 1, 2], out)
+    res = mem.to_host(out)
+    for b in (0, 2):
+        assert (res[b] == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[b, :ncw[b]], b)).all(), knobs

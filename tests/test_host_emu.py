@@ -221,3 +221,23 @@ def test_reference_n65536_29_prime_context_is_accepted(orc, api, emu_lib, mem):
     X.ntt(d, 28, 0, 28, False)
     X.ntt(d, 28, 0, 28, True)
     assert (mem.to_host(d) == a).all()
+
+
+@pytest.mark.parametrize("knobs", [
+    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MACFUSE": "1"}, {"HHE_SIDE": "1"},
+    {"HHE_DIGIT_SUB": "1", "HHE_CHUNK": "4"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"}, {"HHE_GRAPH": "0"},
+])
+def test_every_execution_knob_gives_the_same_words(orc, api, emu_lib, mem, small, monkeypatch, knobs):
+    """chunking / streams / fused-MAC / side-stream / sub-batching / graph knobs only change scheduling"""
+    pt = [(3 * i + 1) % 256 for i in range(300)]
+    cw, ncw = small.sym_blocks(orc, pt)
+    refs = [small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[b, :ncw[b]], b) for b in range(3)]
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    small.load_keys(X)
+    out = mem.empty((3,) + small.O.ct_shape)
+    X.transcipher(mem.to_dev(small.enc_key), cw, ncw, [0, 1, 2], out)
+    res = mem.to_host(out)
+    for b in range(3):
+        assert (res[b] == refs[b]).all(), knobs
