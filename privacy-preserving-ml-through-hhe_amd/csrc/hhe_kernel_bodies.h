@@ -27,12 +27,7 @@ template <> struct NttSchedV<1, 5> { static constexpr int R = 2; static constexp
 template <> struct NttSchedV<1, 6> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
 template <> struct NttSchedV<1, 7> { static constexpr int R = 3; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
 template <> struct NttSchedV<1, 8> { static constexpr int R = 3; static constexpr int rho(int i) { return i == 2 ? 2 : 3; } };
-#ifndef HHE_PASS_V
-#define HHE_PASS_V 0   // geometry of the stand-alone NTT passes (1 = small tiles, for occupancy experiments)
-#endif
-template <int LOGM> using NttSched = NttSchedV<HHE_PASS_V, LOGM>;
-constexpr int NTT_TILE_LOG = NttTile<HHE_PASS_V>::LOG;
-constexpr int NTT_LDS_ELEMS = (1 << NTT_TILE_LOG) + 512;  // rows of pitch C+1
+template <int V> struct NttLds { static constexpr int ELEMS = (1 << NttTile<V>::LOG) + 512; };  // rows of pitch C+1
 
 HD u32 bitrev_n(u32 v, int bits)
 {

@@ -66,14 +66,15 @@ int rt_graph_launch(void *exec, rt_stream s) { return rt_check(hipGraphLaunch((h
 void rt_graph_destroy(void *exec) { if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec); }
 
 // ---------------------------------------------------------------- NTT
-template <int LOGM, bool STRIDED, bool INVERSE, int R>
+template <int V, int LOGM, bool STRIDED, bool INVERSE>
 struct NttRounds {
+    static constexpr int R = NttSchedV<V, LOGM>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
     template <int I, int S0>
     static __device__ __forceinline__ void fwd(const NttArgs &a, u64 *lds)
     {
         if constexpr (I < R) {
-            constexpr int RHO = NttSched<LOGM>::rho(I);
+            constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
             ntt_body_round<LOGM, S0, RHO, STRIDED, false>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
             __syncthreads();
             fwd<I + 1, S0 + RHO>(a, lds);
@@ -83,7 +84,7 @@ struct NttRounds {
     static __device__ __forceinline__ void inv(const NttArgs &a, u64 *lds)
     {
         if constexpr (I >= 0) {
-            constexpr int RHO = NttSched<LOGM>::rho(I);
+            constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
             ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
             __syncthreads();
             inv<I - 1, SEND - RHO>(a, lds);
@@ -91,40 +92,49 @@ struct NttRounds {
     }
 };
 
-#ifndef NTT_WAVES_PER_SIMD
-#define NTT_WAVES_PER_SIMD (HHE_PASS_V == 0 ? 4 : 6)
-#endif
-template <int LOGM, bool STRIDED, bool INVERSE>
-__global__ void __launch_bounds__(NTT_THREADS, NTT_WAVES_PER_SIMD) ntt_pass_kernel(NttArgs a)
+// V = 0: 4096-point tiles (bulk launches); V = 1: 2048-point tiles -- twice the workgroups, half the lifetime each,
+// used when a launch would not even fill the 1024 resident workgroup slots once (latency-bound small batches)
+template <int V, int LOGM, bool STRIDED, bool INVERSE>
+__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
 {
-    __shared__ u64 lds[NTT_LDS_ELEMS];
+    __shared__ u64 lds[NttLds<V>::ELEMS];
     ntt_body_load<STRIDED, INVERSE>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
     __syncthreads();
-    constexpr int R = NttSched<LOGM>::R;
     if (!(a.probe & 4)) {  // probe bit 2: timing probe that skips the butterflies (memory pattern only)
-        if constexpr (!INVERSE) NttRounds<LOGM, STRIDED, INVERSE, R>::template fwd<0, 0>(a, lds);
-        else NttRounds<LOGM, STRIDED, INVERSE, R>::template inv<R - 1, LOGM>(a, lds);
+        if constexpr (!INVERSE) NttRounds<V, LOGM, STRIDED, INVERSE>::template fwd<0, 0>(a, lds);
+        else NttRounds<V, LOGM, STRIDED, INVERSE>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM>(a, lds);
     }
     ntt_body_store<STRIDED, INVERSE>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
 }
 
-template <bool STRIDED, bool INVERSE>
-static void launch_pass(NttArgs a, int logm, int other, hipStream_t st)
+static int g_small_wgs = -1;
+template <int V, bool STRIDED, bool INVERSE>
+static void launch_pass_v(NttArgs a, int logm, int other, hipStream_t st)
 {
     a.logm = logm;
-    int logc = NTT_TILE_LOG - logm;
+    int logc = NttTile<V>::LOG - logm;
     if (logc > other) logc = other;
     a.logc = logc;
     dim3 grid(1u << (other - logc), (unsigned)a.count);
     static int dyn_lds = -1;  // occupancy probe: extra dynamic LDS per workgroup (HHE_NTT_DYNLDS bytes)
     if (dyn_lds < 0) { const char *e = getenv("HHE_NTT_DYNLDS"); dyn_lds = e ? atoi(e) : 0; }
     switch (logm) {
-    case 5: hipLaunchKernelGGL((ntt_pass_kernel<5, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
-    case 6: hipLaunchKernelGGL((ntt_pass_kernel<6, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
-    case 7: hipLaunchKernelGGL((ntt_pass_kernel<7, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
-    case 8: hipLaunchKernelGGL((ntt_pass_kernel<8, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
+    case 5: hipLaunchKernelGGL((ntt_pass_kernel<V, 5, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
+    case 6: hipLaunchKernelGGL((ntt_pass_kernel<V, 6, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
+    case 7: hipLaunchKernelGGL((ntt_pass_kernel<V, 7, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
+    case 8: hipLaunchKernelGGL((ntt_pass_kernel<V, 8, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
     default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", logm); break;
     }
+}
+template <bool STRIDED, bool INVERSE>
+static void launch_pass(const NttArgs &a, int logm, int other, hipStream_t st)
+{
+    if (g_small_wgs < 0) { const char *e = getenv("HHE_NTT_SMALL"); g_small_wgs = e ? atoi(e) : 0;  // measured: no gain on MI355X, off by default }
+    int logc0 = NttTile<0>::LOG - logm;
+    if (logc0 > other) logc0 = other;
+    const long long wgs0 = ((long long)1 << (other - logc0)) * a.count;
+    if (wgs0 < g_small_wgs && (1 << a.logn) > (1 << NttTile<1>::LOG)) launch_pass_v<1, STRIDED, INVERSE>(a, logm, other, st);
+    else launch_pass_v<0, STRIDED, INVERSE>(a, logm, other, st);
 }
 template <int LOGM, int I, int S0>
 static __device__ __forceinline__ void dmac_rounds(const NttArgs &a, int bx, int by, u64 *lds)

@@ -32,55 +32,67 @@ void *rt_capture_end(rt_stream) { return nullptr; }
 int rt_graph_launch(void *, rt_stream) { return -1; }
 void rt_graph_destroy(void *) {}
 
-template <int LOGM, bool STRIDED, bool INVERSE, int I, int S0>
+template <int V, int LOGM, bool STRIDED, bool INVERSE, int I, int S0>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
 {
-    if constexpr (I < NttSched<LOGM>::R) {
-        constexpr int RHO = NttSched<LOGM>::rho(I);
+    if constexpr (I < NttSchedV<V, LOGM>::R) {
+        constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
         for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false>(a, bx, by, t, lds);
-        rounds_fwd<LOGM, STRIDED, INVERSE, I + 1, S0 + RHO>(a, bx, by, lds);
+        rounds_fwd<V, LOGM, STRIDED, INVERSE, I + 1, S0 + RHO>(a, bx, by, lds);
     }
 }
-template <int LOGM, bool STRIDED, bool INVERSE, int I, int SEND>
+template <int V, int LOGM, bool STRIDED, bool INVERSE, int I, int SEND>
 static void rounds_inv(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (I >= 0) {
-        constexpr int RHO = NttSched<LOGM>::rho(I);
+        constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
         for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true>(a, bx, by, t, lds);
-        rounds_inv<LOGM, STRIDED, INVERSE, I - 1, SEND - RHO>(a, bx, by, lds);
+        rounds_inv<V, LOGM, STRIDED, INVERSE, I - 1, SEND - RHO>(a, bx, by, lds);
     }
 }
-template <int LOGM, bool STRIDED, bool INVERSE>
+template <int V, int LOGM, bool STRIDED, bool INVERSE>
 static void pass_emu(const NttArgs &a, int gx, int gy)
 {
 #pragma omp parallel
     {
-        std::vector<u64> lds(NTT_LDS_ELEMS);
+        std::vector<u64> lds(NttLds<V>::ELEMS);
 #pragma omp for collapse(2)
         for (int by = 0; by < gy; by++)
             for (int bx = 0; bx < gx; bx++) {
                 for (int t = 0; t < NTT_THREADS; t++) ntt_body_load<STRIDED, INVERSE>(a, bx, by, t, lds.data());
-                if constexpr (!INVERSE) rounds_fwd<LOGM, STRIDED, INVERSE, 0, 0>(a, bx, by, lds.data());
-                else rounds_inv<LOGM, STRIDED, INVERSE, NttSched<LOGM>::R - 1, LOGM>(a, bx, by, lds.data());
+                if constexpr (!INVERSE) rounds_fwd<V, LOGM, STRIDED, INVERSE, 0, 0>(a, bx, by, lds.data());
+                else rounds_inv<V, LOGM, STRIDED, INVERSE, NttSchedV<V, LOGM>::R - 1, LOGM>(a, bx, by, lds.data());
                 for (int t = 0; t < NTT_THREADS; t++) ntt_body_store<STRIDED, INVERSE>(a, bx, by, t, lds.data());
             }
     }
 }
-template <bool STRIDED, bool INVERSE>
-static void launch_pass(NttArgs a, int logm, int other)
+template <int V, bool STRIDED, bool INVERSE>
+static void launch_pass_v(NttArgs a, int logm, int other)
 {
     a.logm = logm;
-    int logc = NTT_TILE_LOG - logm;
+    int logc = NttTile<V>::LOG - logm;
     if (logc > other) logc = other;
     a.logc = logc;
     const int gx = 1 << (other - logc), gy = a.count;
     switch (logm) {
-    case 5: pass_emu<5, STRIDED, INVERSE>(a, gx, gy); break;
-    case 6: pass_emu<6, STRIDED, INVERSE>(a, gx, gy); break;
-    case 7: pass_emu<7, STRIDED, INVERSE>(a, gx, gy); break;
-    case 8: pass_emu<8, STRIDED, INVERSE>(a, gx, gy); break;
+    case 5: pass_emu<V, 5, STRIDED, INVERSE>(a, gx, gy); break;
+    case 6: pass_emu<V, 6, STRIDED, INVERSE>(a, gx, gy); break;
+    case 7: pass_emu<V, 7, STRIDED, INVERSE>(a, gx, gy); break;
+    case 8: pass_emu<V, 8, STRIDED, INVERSE>(a, gx, gy); break;
     default: fprintf(stderr, "emu: unsupported pass size\n"); abort();
     }
+}
+// same geometry selection as hhe_kernels.hip (HHE_NTT_SMALL: workgroup-count threshold below which 2048-point tiles are used)
+template <bool STRIDED, bool INVERSE>
+static void launch_pass(const NttArgs &a, int logm, int other)
+{
+    const char *e = getenv("HHE_NTT_SMALL");
+    const int small_wgs = e ? atoi(e) : 0;
+    int logc0 = NttTile<0>::LOG - logm;
+    if (logc0 > other) logc0 = other;
+    const long long wgs0 = ((long long)1 << (other - logc0)) * a.count;
+    if (wgs0 < small_wgs && (1 << a.logn) > (1 << NttTile<1>::LOG)) launch_pass_v<1, STRIDED, INVERSE>(a, logm, other);
+    else launch_pass_v<0, STRIDED, INVERSE>(a, logm, other);
 }
 template <int LOGM, int I, int S0>
 static void dmac_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds)

@@ -241,3 +241,11 @@ def test_every_execution_knob_gives_the_same_words(orc, api, emu_lib, mem, small
     res = mem.to_host(out)
     for b in range(3):
         assert (res[b] == refs[b]).all(), knobs
+
+
+def test_small_tile_geometry_of_the_ntt_passes(orc, api, emu_lib, mem, monkeypatch):
+    """HHE_NTT_SMALL selects 2048-point tiles for launches with few workgroups: same transform"""
+    monkeypatch.setenv("HHE_NTT_SMALL", "100000")
+    for logn, bits in ((12, [55] * 2), (13, [60] * 2), (15, [60] * 2)):
+        q = orc.coeff_modulus_create(1 << logn, bits)
+        pc.check_ntt(api.Context(logn, q, T, lib=emu_lib), orc.Oracle(logn, q, T), mem, seed=logn)
