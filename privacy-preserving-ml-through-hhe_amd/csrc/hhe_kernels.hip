@@ -129,7 +129,7 @@ static void launch_pass_v(NttArgs a, int logm, int other, hipStream_t st)
 template <bool STRIDED, bool INVERSE>
 static void launch_pass(const NttArgs &a, int logm, int other, hipStream_t st)
 {
-    if (g_small_wgs < 0) { const char *e = getenv("HHE_NTT_SMALL"); g_small_wgs = e ? atoi(e) : 0;  // measured: no gain on MI355X, off by default }
+    if (g_small_wgs < 0) { const char *e = getenv("HHE_NTT_SMALL"); g_small_wgs = e ? atoi(e) : 0; }  // measured: no gain on MI355X, off by default
     int logc0 = NttTile<0>::LOG - logm;
     if (logc0 > other) logc0 = other;
     const long long wgs0 = ((long long)1 << (other - logc0)) * a.count;
