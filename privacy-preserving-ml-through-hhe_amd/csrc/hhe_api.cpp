@@ -93,6 +93,7 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
     const int L = c->L, K = c->K;
     NttArgs a = ntt_args(c, d, c->w->ws_T, B * L * K, 0, K);
     a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = d_stride; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+    a.store_op = STORE_LAZY;  // ks_mac reduces: digits may stay in [0,4q)
     k_ntt(a, false, c->w->stream);
     KsMacArgs m;
     memset(&m, 0, sizeof(m));
@@ -407,6 +408,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
                 const size_t bs = std::min(sub, B - o);
                 NttArgs a = ntt_args(c, c->w->ws_d + o * ln, c->w->ws_T, bs * L * K, 0, K);
                 a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+                a.store_op = STORE_LAZY;
                 KsMacArgs m;
                 memset(&m, 0, sizeof(m));
                 m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S + o * 2 * K * n; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)bs; m.L = L; m.K = K;

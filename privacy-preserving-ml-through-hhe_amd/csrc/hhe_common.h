@@ -37,7 +37,8 @@ enum NttStoreOp {
     STORE_PLAIN = 0, STORE_MUL = 1, STORE_SCALE_T = 2, STORE_MAC = 3,
     STORE_RSP = 5,         // inv (special limb): v + floor(q_sp/2) mod q_sp
     STORE_KS1 = 6,         // inv: (v - r_1 + half) * q_sp^-1, written through the Galois map into aux_out
-    STORE_KS0 = 7          // fwd: NTT-domain key-switch finish of c0 + permuted-frame diagonal MAC
+    STORE_KS0 = 7,         // fwd: NTT-domain key-switch finish of c0 + permuted-frame diagonal MAC
+    STORE_LAZY = 8         // fwd: leave the result in the lazy range [0,4q) (consumer reduces: key-switch inner product)
 };
 
 // key-switch mod-down constants, passed by value to the kernels that finish a key switch

@@ -199,7 +199,7 @@ HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds
         ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
         u64 v[2] = {lds[l0], lds[l1]};
         if (a.store_op == 99) { if (v[0] == 0x123456789abcdefULL) dst[gi] = v[0]; continue; }  // timing probe (no global write)
-        if (!LAST) { st2(dst + gi, U2{v[0], v[1]}); continue; }
+        if (!LAST || (!INVERSE && a.store_op == STORE_LAZY)) { st2(dst + gi, U2{v[0], v[1]}); continue; }
         if (INVERSE) {
             const bool st = a.store_op == STORE_SCALE_T;
             for (int k = 0; k < 2; k++) {
