@@ -805,8 +805,27 @@ int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, co
 }
 }  // namespace
 
+static int fc_row_chunk(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
+                        int default_galois_only, uint64_t *out, size_t B);
+
 extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
                           int default_galois_only, uint64_t *out, size_t B)
+{
+    if (!c || W == 0) return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
+    // chunks keep the key-switch working set (digit transforms) inside the Infinity Cache; a chunk is a multiple of W
+    // so that item i of a chunk still uses weight row i % W
+    size_t per = c->fc_chunk ? c->fc_chunk : B;
+    if (per < B) per = std::max<size_t>(W, per / W * W);
+    for (size_t b0 = 0; b0 < B; b0 += per) {
+        const size_t bc = std::min(per, B - b0);
+        int rc = fc_row_chunk(c, vi + b0 * c->ct_words(), w, W, n_inputs, relin_slot, default_galois_only, out + b0 * c->ct_words(), bc);
+        if (rc) return rc;
+    }
+    return HHE_OK;
+}
+
+static int fc_row_chunk(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
+                        int default_galois_only, uint64_t *out, size_t B)
 {
     if (!c || !vi || !w || !out || W == 0 || n_inputs == 0 || n_inputs > c->n / 2 || relin_slot < 0 || relin_slot >= HHE_RELIN_SLOTS)
         return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
