@@ -56,6 +56,7 @@ struct NttArgs {
     int logn;
     int logm;       // log2 of this pass's sub-transform size
     int logc;       // log2 lanes (independent sub-transforms) per tile
+    int tiles_log;  // log2 tiles per polynomial in this pass (1-D grid decode)
     int count;      // polynomials in the batch
     int mod_base, mod_cycle;  // modulus of poly p = mod_base + p % mod_cycle
     // source poly of p: src + (p / src_item_polys) * src_item_stride + ((p % src_item_polys) / src_div) * N

@@ -31,7 +31,11 @@ int rt_h2d(void *d, const void *s, size_t n, rt_stream st) { return rt_check(hip
 int rt_d2h(void *d, const void *s, size_t n, rt_stream st) { return rt_check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st), "d2h"); }
 int rt_d2d(void *d, const void *s, size_t n, rt_stream st) { return rt_check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st), "d2d"); }
 int rt_memset(void *d, int v, size_t n, rt_stream st) { return rt_check(hipMemsetAsync(d, v, n, (hipStream_t)st), "memset"); }
-int rt_sync(rt_stream st) { return rt_check(hipStreamSynchronize((hipStream_t)st), "sync"); }
+int rt_sync(rt_stream st)
+{
+    if (rt_check(hipStreamSynchronize((hipStream_t)st), "sync")) return -1;
+    return rt_check(hipGetLastError(), "kernel launch");  // a rejected launch (bad grid, missing code object) must not pass silently
+}
 rt_stream rt_stream_create()
 {
     hipStream_t s = nullptr;
@@ -66,6 +70,10 @@ int rt_graph_launch(void *exec, rt_stream s) { return rt_check(hipGraphLaunch((h
 void rt_graph_destroy(void *exec) { if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec); }
 
 // ---------------------------------------------------------------- NTT
+// one-dimensional grids (gridDim.y is limited to 65535 polynomials): block -> (tile, poly), tiles per poly = 2^tiles_log
+#define NTT_BX(a) ((int)(blockIdx.x & ((1u << (a).tiles_log) - 1)))
+#define NTT_BY(a) ((int)(blockIdx.x >> (a).tiles_log))
+
 template <int V, int LOGM, bool STRIDED, bool INVERSE>
 struct NttRounds {
     static constexpr int R = NttSchedV<V, LOGM>::R;
@@ -75,7 +83,7 @@ struct NttRounds {
     {
         if constexpr (I < R) {
             constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
             __syncthreads();
             fwd<I + 1, S0 + RHO>(a, lds);
         }
@@ -85,7 +93,7 @@ struct NttRounds {
     {
         if constexpr (I >= 0) {
             constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
             __syncthreads();
             inv<I - 1, SEND - RHO>(a, lds);
         }
@@ -98,13 +106,13 @@ template <int V, int LOGM, bool STRIDED, bool INVERSE>
 __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
 {
     __shared__ u64 lds[NttLds<V>::ELEMS];
-    ntt_body_load<STRIDED, INVERSE>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    ntt_body_load<STRIDED, INVERSE>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
     __syncthreads();
     if (!(a.probe & 4)) {  // probe bit 2: timing probe that skips the butterflies (memory pattern only)
         if constexpr (!INVERSE) NttRounds<V, LOGM, STRIDED, INVERSE>::template fwd<0, 0>(a, lds);
         else NttRounds<V, LOGM, STRIDED, INVERSE>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM>(a, lds);
     }
-    ntt_body_store<STRIDED, INVERSE>(a, blockIdx.x, blockIdx.y, threadIdx.x, lds);
+    ntt_body_store<STRIDED, INVERSE>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
 }
 
 static int g_small_wgs = -1;
@@ -115,7 +123,8 @@ static void launch_pass_v(NttArgs a, int logm, int other, hipStream_t st)
     int logc = NttTile<V>::LOG - logm;
     if (logc > other) logc = other;
     a.logc = logc;
-    dim3 grid(1u << (other - logc), (unsigned)a.count);
+    a.tiles_log = other - logc;
+    dim3 grid((unsigned)(((size_t)a.count) << a.tiles_log));
     static int dyn_lds = -1;  // occupancy probe: extra dynamic LDS per workgroup (HHE_NTT_DYNLDS bytes)
     if (dyn_lds < 0) { const char *e = getenv("HHE_NTT_DYNLDS"); dyn_lds = e ? atoi(e) : 0; }
     switch (logm) {
@@ -153,16 +162,17 @@ __global__ void __launch_bounds__(NTT_THREADS) digit_mac_kernel(NttArgs a, KsMac
     u64 acc0[2 * DMAC_NPAIR], acc1[2 * DMAC_NPAIR];
 #pragma unroll
     for (int k = 0; k < 2 * DMAC_NPAIR; k++) { acc0[k] = 0; acc1[k] = 0; }
-    const int b = blockIdx.y / a.K, J = blockIdx.y % a.K;
+    const int bxx = NTT_BX(a), byy = NTT_BY(a);
+    const int b = byy / a.K, J = byy % a.K;
     for (int I = 0; I < a.L; I++) {
         const int by = (b * a.L + I) * a.K + J;
-        ntt_body_load<false, false>(a, blockIdx.x, by, threadIdx.x, lds);
+        ntt_body_load<false, false>(a, bxx, by, threadIdx.x, lds);
         __syncthreads();
-        dmac_rounds<LOGM, 0, 0>(a, blockIdx.x, by, lds);
-        digit_mac_phase(a, mk, blockIdx.x, by, I, threadIdx.x, lds, acc0, acc1);
+        dmac_rounds<LOGM, 0, 0>(a, bxx, by, lds);
+        digit_mac_phase(a, mk, bxx, by, I, threadIdx.x, lds, acc0, acc1);
         __syncthreads();
     }
-    digit_mac_store(a, mk, blockIdx.x, b * a.L * a.K + J, threadIdx.x, acc0, acc1);
+    digit_mac_store(a, mk, bxx, b * a.L * a.K + J, threadIdx.x, acc0, acc1);
 }
 void k_digit_mac(const NttArgs &a0, const KsMacArgs &mk, rt_stream s)
 {
@@ -173,7 +183,8 @@ void k_digit_mac(const NttArgs &a0, const KsMacArgs &mk, rt_stream s)
     int logc = NttTile<1>::LOG - n2;
     if (logc > n1) logc = n1;
     a.logc = logc;
-    dim3 grid(1u << (n1 - logc), (unsigned)(mk.B * mk.K));
+    a.tiles_log = n1 - logc;
+    dim3 grid((unsigned)(((size_t)mk.B * mk.K) << a.tiles_log));
     hipStream_t st = (hipStream_t)s;
     switch (n2) {
     case 5: hipLaunchKernelGGL((digit_mac_kernel<5>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
