@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="transcipherings per rank per step")
     ap.add_argument("--workload", default="config2", choices=["config2", "mnist"],
                     help="config2: all blocks use counter 0 (BASELINE metric); mnist: 784-word samples = blocks 0..6 (last ragged)")
+    ap.add_argument("--params", default="config2", choices=["config2", "default16384"],
+                    help="config2: N=2^15, 4x60-bit (BASELINE metric); default16384: the reference's defaults N=2^14, BFVDefault 9 primes")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-blocks-per-thread", type=int, default=2)
     args = ap.parse_args()
@@ -70,10 +72,14 @@ def main():
     torch.cuda.set_device(local_rank)
     lib = api.load_library()
 
+    logn = LOGN
     n, q, t = 1 << LOGN, Q_CONFIG2, T_PLAIN
+    if args.params == "default16384":
+        logn, n = 14, 1 << 14
+        q = api.bfv_default_coeff_modulus(n, lib)
     K, L = len(q), len(q) - 1
     B = args.batch
-    X = api.Context(LOGN, q, t, device=local_rank, lib=lib)
+    X = api.Context(logn, q, t, device=local_rank, lib=lib)
     stream = torch.cuda.Stream(device=dev)
     X.set_stream(stream.cuda_stream)
     rng = np.random.default_rng(1234)
@@ -146,14 +152,15 @@ def main():
         path_ms = dev_ms / args.steps
         traffic = None  # HBM-side bytes per launch of the path from rocprofv3 PMC passes (tools/pmc_traffic.py)
         tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_b256_final.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and args.params == "config2":
             traffic = json.load(open(tf))["traffic_bytes_per_transciphering"] * B
         achieved = A * B / (path_ms * 1e-3) / 1e9
         res = {
-            "metric": "PASTA-3 transcipherings/sec (N=2^15, 4 RNS limbs)", "value": value, "unit": "transcipherings/s",
+            "metric": "PASTA-3 transcipherings/sec (N=2^15, 4 RNS limbs)" if args.params == "config2" else "PASTA-3 transcipherings/sec (N=2^14, BFVDefault 9 primes)", "value": value, "unit": "transcipherings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("BASELINE config 2: N=2^15, coeff_modulus 4x60-bit (L=3,K=4), t=65537, "
+            "config": {"workload": (f"reference defaults: N=2^14, BFVDefault 9 primes (L=8,K=9), t=65537, batch-{B} blocks per GPU") if args.params != "config2" else
+                                   ("BASELINE config 2: N=2^15, coeff_modulus 4x60-bit (L=3,K=4), t=65537, "
                                     f"batch-{B} independent 128-word PASTA-3 blocks per GPU, block counter 0") if args.workload == "config2" else
                                    (f"MNIST-shaped: N=2^15, 4x60-bit, t=65537, batch-{B} blocks per GPU = 784-word samples x 7 block counters (last block 16 words)"),
                        "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective"},
@@ -168,7 +175,7 @@ def main():
         }
         if world == 1 and args.cpu_baseline:
             import oracle as orc  # CPU baseline leg only
-            O = orc.Oracle(LOGN, q, t)
+            O = orc.Oracle(logn, q, t)
             threads = min(16, len(os.sched_getaffinity(0)))  # the GPU box grants 16 cores per GPU
             nb = threads * args.cpu_blocks_per_thread
             elts = sorted(gks)
