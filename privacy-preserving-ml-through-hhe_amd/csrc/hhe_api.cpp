@@ -790,16 +790,56 @@ struct NafNode {
     int mult = 0;                 // how many i end exactly here
     std::vector<int> kids;
 };
-int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out, size_t B)
+struct FcLeafAcc {  // sums over the leaves of the trie (DESIGN.md "FC rotation trie")
+    u64 *accG, *accS, *accH, *rscr;
+};
+// A leaf's ciphertext is only ever added into the result.  Key switching is linear up to the rounding term, so for
+// leaves the inverse transforms of S_k[j] are postponed: sum S_k[j] over all leaves in the NTT domain, sum the rounding
+// terms half_j - (r_k mod q_j) and galois(c0) in the coefficient domain, inverse-transform once (14 instead of 20
+// transforms per leaf; identical words because every step is exact modular arithmetic).
+int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t B)
+{
+    auto it = c->d_gk.find(elt);
+    if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    const int L = c->L, K = c->K;
+    const size_t n = c->n, ln = (size_t)L * n;
+    GaloisArgs g;
+    memset(&g, 0, sizeof(g));
+    g.mods = c->d_mods; g.logn = c->logn; g.count = (int)(B * L); g.L = L; g.einv = (u32)nt_invmod(elt, 2 * n);
+    g.in = parent; g.in_item_stride = 2 * ln; g.out = acc.accG; g.out_item_stride = ln; g.accumulate = 1;
+    k_galois(g, c->w->stream);
+    g.in = parent + ln; g.out = c->w->ws_d; g.accumulate = 0;
+    k_galois(g, c->w->stream);
+    NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
+    a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+    a.store_op = STORE_LAZY;
+    k_ntt(a, false, c->w->stream);
+    KsMacArgs m;
+    memset(&m, 0, sizeof(m));
+    m.T = c->w->ws_T; m.key = it->second; m.S = c->w->ws_S; m.s_acc = acc.accS; m.mods = c->d_mods; m.logn = c->logn;
+    m.B = (int)B; m.L = L; m.K = K;
+    k_ks_mac(m, c->w->stream);
+    NttArgs r = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, acc.rscr, B * 2, K - 1, 1);
+    r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RACC; r.acc = acc.accH;
+    k_ntt(r, true, c->w->stream);
+    return HHE_OK;
+}
+int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out,
+           const FcLeafAcc *acc, size_t B)
 {
     const size_t ctw = c->ct_words();
     for (int kid : trie[node].kids) {
-        u64 *cur = bufs + (size_t)depth * B * ctw;
         const u32 elt = galois_elt_from_step(c, trie[kid].term);
+        if (acc && trie[kid].kids.empty() && trie[kid].mult == 1) {
+            int rc = fc_leaf(c, parent, elt, *acc, B);
+            if (rc) return rc;
+            continue;
+        }
+        u64 *cur = bufs + (size_t)depth * B * ctw;
         int rc = op_apply_galois(c, parent, elt, cur, B);
         if (rc) return rc;
         for (int m = 0; m < trie[kid].mult; ++m) op_add(c, out, cur, out, B, 2);
-        if ((rc = fc_dfs(c, trie, kid, depth + 1, cur, bufs, out, B))) return rc;
+        if ((rc = fc_dfs(c, trie, kid, depth + 1, cur, bufs, out, acc, B))) return rc;
     }
     return HHE_OK;
 }
@@ -882,5 +922,19 @@ static int fc_row_chunk(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_
     c->d_rk = saved;
     if (rc) return rc;
     rt_d2d(out, prod, B * ctw * 8, ln.stream);
-    return fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, B);
+    if (!c->fc_leaf_sums) return fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, nullptr, B);
+    const size_t bln = B * (size_t)L * c->n;
+    FcLeafAcc acc;
+    acc.accS = ln.ws_ct[0]; acc.accH = ln.ws_ct[1]; acc.accG = ln.ws_ct[2]; acc.rscr = ln.ws_ct[2] + bln;
+    rt_memset(acc.accS, 0, 2 * bln * 8, ln.stream);
+    rt_memset(acc.accH, 0, 2 * bln * 8, ln.stream);
+    rt_memset(acc.accG, 0, bln * 8, ln.stream);
+    if ((rc = fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, &acc, B))) return rc;
+    op_ntt(c, acc.accS, B * 2 * L, 0, L, true);
+    LeafSumArgs ls;
+    memset(&ls, 0, sizeof(ls));
+    ls.accG = acc.accG; ls.accS = acc.accS; ls.accH = acc.accH; ls.out = out; ls.mods = c->d_mods; ls.logn = c->logn;
+    ls.B = (int)B; ls.L = L; ls.ks = c->ksc;
+    k_leaf_sum(ls, ln.stream);
+    return HHE_OK;
 }

@@ -38,6 +38,7 @@ enum NttStoreOp {
     STORE_RSP = 5,         // inv (special limb): v + floor(q_sp/2) mod q_sp
     STORE_KS1 = 6,         // inv: (v - r_1 + half) * q_sp^-1, written through the Galois map into aux_out
     STORE_KS0 = 7,         // fwd: NTT-domain key-switch finish of c0 + permuted-frame diagonal MAC
+    STORE_RACC = 9,        // inv (special limb): r = v + half mod q_sp, then acc[b][k][j] += half_j - (r mod q_j) for every data limb j
     STORE_LAZY = 8         // fwd: leave the result in the lazy range [0,4q) (consumer reduces: key-switch inner product)
 };
 
@@ -100,6 +101,7 @@ struct GaloisArgs {  // out[p][k] = +-in[p][k * einv mod 2N]; poly p = (item b, 
     int logn, count, L;
     size_t in_item_stride, out_item_stride;  // words between items
     u32 einv;  // elt^-1 mod 2N
+    int accumulate;  // 1: out += gathered value (mod q) instead of out = value
 };
 
 struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
@@ -108,6 +110,8 @@ struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
     u64 *S;          // [B][2][K][N]
     const ModDev *mods;
     int logn, B, L, K;
+    // optional (FC leaf sums): for J < L the products are added into s_acc[b][k][J][n] instead of being written to S
+    u64 *s_acc;
     // optional (fused matmul): acc[b][J][n] += T[b][J][J][n] * mul_ptrs[b][mul_shift + J*N + n] for J < L
     u64 *acc;
     const u64 *const *mul_ptrs;
@@ -124,6 +128,16 @@ struct PermArgs {  // NTT-domain Galois permutation: out[p][x] (op)= in[p][pi_el
     int mac;                   // 1: out[p][x] += in[p][pi(x)] * mul_ptrs[b][shift + j*N + x]
     const u64 *const *mul_ptrs;
     size_t mul_shift;
+};
+
+struct LeafSumArgs {  // out[b][k][j] += (k == 0 ? accG[b][j] : 0) + qsp_inv_j * (accS[b][k][j] (INTT'd) + accH[b][k][j])
+    const u64 *accG;  // [B][L][N] sum of galois(c0) of the leaf parents
+    const u64 *accS;  // [B][2][L][N] coefficient form (after INTT)
+    const u64 *accH;  // [B][2][L][N]
+    u64 *out;         // [B][2][L][N]
+    const ModDev *mods;
+    int logn, B, L;
+    KsConsts ks;
 };
 
 struct KsFinishArgs {  // SURVEY A.4 mod-down; S already INTT'd (coefficient form)

@@ -206,7 +206,18 @@ HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds
                 v[k] = shoup_lazy(v[k], st ? m.ninv_t : m.ninv, st ? m.ninv_t_s : m.ninv_s, q);
                 v[k] -= (v[k] >= q) ? q : 0;
             }
-            if (a.store_op == STORE_RSP) { v[0] = addmod(v[0], a.ks.half, q); v[1] = addmod(v[1], a.ks.half, q); }
+            if (a.store_op == STORE_RSP || a.store_op == STORE_RACC) { v[0] = addmod(v[0], a.ks.half, q); v[1] = addmod(v[1], a.ks.half, q); }
+            if (a.store_op == STORE_RACC) {  // poly = (item, k): rounding terms of a leaf key switch, summed per data limb
+                for (int j = 0; j < a.L; j++) {
+                    const ModDev &mj = a.mods[j];
+                    u64 *ap = a.acc + ((size_t)g.poly * a.L + j) * g.n + gi;
+                    U2 ac = ld2(ap);
+                    ac.a = addmod(ac.a, submod(a.ks.half_mod[j], reduce64(v[0], mj), mj.q), mj.q);
+                    ac.b = addmod(ac.b, submod(a.ks.half_mod[j], reduce64(v[1], mj), mj.q), mj.q);
+                    st2(ap, ac);
+                }
+                continue;
+            }
             else if (a.store_op == STORE_KS1) {
                 const int j = g.poly % a.L;
                 const size_t item = g.poly / a.L;
@@ -300,7 +311,8 @@ HD void galois_body(const GaloisArgs &a, size_t gid)
     const u32 j = (u32)(((u64)k * a.einv) & (2 * n - 1));
     const u64 *src = a.in + item * a.in_item_stride + limb * n;
     u64 v = (j < n) ? src[j] : negmod(src[j - n], q);
-    a.out[item * a.out_item_stride + limb * n + k] = v;
+    u64 *o = a.out + item * a.out_item_stride + limb * n + k;
+    *o = a.accumulate ? addmod(*o, v, q) : v;
 }
 
 // NTT-domain Galois gather, optionally multiply-accumulating with a per-item table: gid over [count][N]
@@ -350,8 +362,18 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
             }
         }
     }
-    st2(a.S + ((b * 2 + 0) * a.K + J) * n + i, U2{barrett128(s0[0].lo, s0[0].hi, m), barrett128(s0[1].lo, s0[1].hi, m)});
-    st2(a.S + ((b * 2 + 1) * a.K + J) * n + i, U2{barrett128(s1[0].lo, s1[0].hi, m), barrett128(s1[1].lo, s1[1].hi, m)});
+    const U2 r0 = {barrett128(s0[0].lo, s0[0].hi, m), barrett128(s0[1].lo, s0[1].hi, m)};
+    const U2 r1 = {barrett128(s1[0].lo, s1[0].hi, m), barrett128(s1[1].lo, s1[1].hi, m)};
+    if (a.s_acc && J < a.L) {  // leaf of the FC rotation trie: only the sum over leaves is ever inverse-transformed
+        u64 *p0 = a.s_acc + ((b * 2 + 0) * a.L + J) * n + i, *p1 = a.s_acc + ((b * 2 + 1) * a.L + J) * n + i;
+        U2 c0 = ld2(p0), c1 = ld2(p1);
+        c0.a = addmod(c0.a, r0.a, m.q); c0.b = addmod(c0.b, r0.b, m.q);
+        c1.a = addmod(c1.a, r1.a, m.q); c1.b = addmod(c1.b, r1.b, m.q);
+        st2(p0, c0); st2(p1, c1);
+        return;
+    }
+    st2(a.S + ((b * 2 + 0) * a.K + J) * n + i, r0);
+    st2(a.S + ((b * 2 + 1) * a.K + J) * n + i, r1);
 }
 
 // Fused digit NTT + key-switch inner product (row pass of NTT_J(d_I mod q_J), V = 1 tiles): after the last
@@ -407,6 +429,23 @@ HD void digit_mac_store(const NttArgs &a, const KsMacArgs &mk, int bx, int by, i
         st2(mk.S + ((b * 2 + 0) * a.K + J) * g.n + gi, U2{acc0[2 * k], acc0[2 * k + 1]});
         st2(mk.S + ((b * 2 + 1) * a.K + J) * g.n + gi, U2{acc1[2 * k], acc1[2 * k + 1]});
     }
+}
+
+// closes the leaf sums of the FC rotation trie: gid over [B][2][L][N]
+HD void leaf_sum_body(const LeafSumArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = gid & (n - 1);
+    size_t r = gid >> a.logn;
+    const int j = (int)(r % a.L); r /= a.L;
+    const int k = (int)(r & 1);
+    const size_t b = r >> 1;
+    if (b >= (size_t)a.B) return;
+    const ModDev &m = a.mods[j];
+    u64 v = addmod(a.accS[gid], a.accH[gid], m.q);
+    v = shoup_mul(v, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], m.q);
+    if (k == 0) v = addmod(v, a.accG[(b * a.L + j) * n + i], m.q);
+    a.out[gid] = addmod(a.out[gid], v, m.q);
 }
 
 // key-switch mod-down by the special prime with rounding: gid over [B][2][L][N]
