@@ -249,3 +249,30 @@ def test_small_tile_geometry_of_the_ntt_passes(orc, api, emu_lib, mem, monkeypat
     for logn, bits in ((12, [55] * 2), (13, [60] * 2), (15, [60] * 2)):
         q = orc.coeff_modulus_create(1 << logn, bits)
         pc.check_ntt(api.Context(logn, q, T, lib=emu_lib), orc.Oracle(logn, q, T), mem, seed=logn)
+
+
+def test_edge_cases_single_word_block_and_large_block_counter(orc, api, emu_lib, mem, small):
+    """ragged extremes: a 1-word block, a full block and a far-away block counter in one batch; empty batch is rejected"""
+    O = small.O
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    small.load_keys(X)
+    counters = [0, (1 << 32) + 5]
+    cw = np.zeros((2, 128), np.uint64)
+    pts = []
+    for i, ctr in enumerate(counters):
+        nw = 1 if i == 0 else 128
+        pt = np.array([(9 * j + 4 + i) % 256 for j in range(nw)], dtype=np.uint64)
+        ks = orc.pasta_keystream(small.t, small.key, ctr)
+        cw[i, :nw] = (pt + ks[:nw]) % small.t
+        pts.append(pt)
+    out = mem.empty((2,) + O.ct_shape)
+    X.transcipher(mem.to_dev(small.enc_key), cw, [1, 128], counters, out)
+    res = mem.to_host(out)
+    for i, ctr in enumerate(counters):
+        nw = len(pts[i])
+        assert (res[i] == O.transcipher_block(small.enc_key, small.rk, small.gk, cw[i, :nw], ctr)).all()
+        assert (O.decode(O.decrypt(small.sk, res[i]))[:nw] == pts[i]).all()
+    with pytest.raises(api.HheError):
+        X.transcipher(mem.to_dev(small.enc_key), np.zeros((0, 128), np.uint64), [], [], out)
+    with pytest.raises(api.HheError):
+        X.transcipher(mem.to_dev(small.enc_key), cw, [129, 128], counters, out)  # more than 128 words in a block
