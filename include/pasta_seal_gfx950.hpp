@@ -147,6 +147,43 @@ public:
         detail::check(hhe_copy_d2h(h, out.words.data(), o.p, w * 8));
     }
 
+    // SEALZpCipher::packed_enc_mul / packed_enc_add / packed_square (SEAL_Cipher.cpp:547-566)
+    void packed_enc_mul(const Ciphertext &e1, const Ciphertext &e2, Ciphertext &destination)
+    {
+        const size_t w = context->ct_words();
+        detail::DevBuf a(w * 8), b(w * 8), o(w / 2 * 3 * 8);
+        hhe_ctx *h = context->handle();
+        detail::check(hhe_copy_h2d(h, a.p, e1.words.data(), w * 8));
+        detail::check(hhe_copy_h2d(h, b.p, e2.words.data(), w * 8));
+        detail::check(hhe_multiply(h, a.u64(), b.u64(), o.u64(), 1));   // Evaluator::multiply -> size 3
+        destination.words.resize(w / 2 * 3);
+        destination.size = 3;
+        detail::check(hhe_copy_d2h(h, destination.words.data(), o.p, w / 2 * 3 * 8));
+    }
+    void packed_enc_add(const Ciphertext &e1, const Ciphertext &e2, Ciphertext &destination)
+    {
+        if (e1.size != e2.size || e1.words.size() != e2.words.size()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        detail::DevBuf a(e1.words.size() * 8), b(e1.words.size() * 8);
+        hhe_ctx *h = context->handle();
+        detail::check(hhe_copy_h2d(h, a.p, e1.words.data(), e1.words.size() * 8));
+        detail::check(hhe_copy_h2d(h, b.p, e2.words.data(), e2.words.size() * 8));
+        detail::check(hhe_add(h, a.u64(), b.u64(), a.u64(), 1, (int)e1.size));
+        destination = e1;
+        detail::check(hhe_copy_d2h(h, destination.words.data(), a.p, e1.words.size() * 8));
+    }
+    void packed_square(Ciphertext &vo, const Ciphertext &vi)  // evaluator.square + relinearize_inplace(he_rk)
+    {
+        const size_t w = context->ct_words();
+        detail::DevBuf a(w * 8), o3(w / 2 * 3 * 8);
+        hhe_ctx *h = context->handle();
+        detail::check(hhe_copy_h2d(h, a.p, vi.words.data(), w * 8));
+        detail::check(hhe_multiply(h, a.u64(), a.u64(), o3.u64(), 1));
+        detail::check(hhe_relinearize(h, o3.u64(), a.u64(), 1));
+        vo.words.resize(w);
+        vo.size = 2;
+        detail::check(hhe_copy_d2h(h, vo.words.data(), a.p, w * 8));
+    }
+
 protected:
     ZpCipherParams params;
     uint64_t plain_mod = 0, mod_degree = 0;

@@ -44,6 +44,14 @@ int main(int argc, char **argv)
             HHE.flatten(blocks, flat);
             fwrite(flat.words.data(), 8, flat.words.size(), o);
         }
+        // packed ops on the first two blocks (SEAL_Cipher.cpp:547-566)
+        pasta::Ciphertext sq, prod, sum;
+        HHE.packed_square(sq, blocks[0]);
+        HHE.packed_enc_mul(blocks[0], blocks[1], prod);
+        HHE.packed_enc_add(blocks[0], blocks[1], sum);
+        fwrite(sq.words.data(), 8, sq.words.size(), o);
+        fwrite(prod.words.data(), 8, prod.words.size(), o);
+        fwrite(sum.words.data(), 8, sum.words.size(), o);
         fclose(o);
         // error behaviour: a context without Galois keys must throw like SEAL does
         pasta::PASTA_SEAL bare(std::make_shared<pasta::HheContext>(logn, q, hdr[2], 0), {}, {}, rk, {});

@@ -40,11 +40,19 @@ def _run(orc, tmp_path, libdir, libname, extra_env=None):
     words = np.fromfile(out, dtype=np.uint64)
     nb = int(words[0])
     assert nb == 3
-    cts = words[1:].reshape(nb + 1, *O.ct_shape)
+    ctw = int(np.prod(O.ct_shape))
+    base = 1 + (nb + 1) * ctw
+    cts = words[1:base].reshape(nb + 1, *O.ct_shape)
+    sq = words[base:base + ctw].reshape(O.ct_shape)
+    prod = words[base + ctw:base + ctw + ctw // 2 * 3].reshape(3, O.L, O.n)
+    ssum = words[base + ctw + ctw // 2 * 3:].reshape(O.ct_shape)
     cw, ncw = S.sym_blocks(orc, pt)
     refs = [O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b) for b in range(nb)]
     for b in range(nb):
         assert (cts[b] == refs[b]).all()
+    assert (sq == O.relinearize(O.multiply(refs[0], refs[0]), S.rk)).all()      # packed_square
+    assert (prod == O.multiply(refs[0], refs[1])).all()                          # packed_enc_mul
+    assert (ssum == O.add(refs[0], refs[1])).all()                               # packed_enc_add
     flat = O.flatten(np.stack(refs), S.gk)
     assert (cts[nb] == flat).all()
     # mask-free flatten decrypts to the record (SEAL_Cipher.cpp:170-181 semantics): first 300 slots
