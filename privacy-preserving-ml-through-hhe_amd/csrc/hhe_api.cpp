@@ -432,7 +432,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
         {   // c1 of the next state, coefficient form, already passed through the Galois map for the next digits
             NttArgs a = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
             a.src_item_polys = L; a.src_item_stride = (size_t)2 * K * n; a.store_op = STORE_KS1;
-            a.aux_r = r; a.aux_out = c->w->ws_d; a.gal_elt = g;
+            a.aux_r = r; a.aux_out = c->w->ws_d; a.gal_elt = (c->probe & 2) ? 0 : g;  // probe bit 1: no Galois scatter (results invalid)
             k_ntt(a, true, c->w->stream);
         }
         {   // c0 of the next state in NTT form + permuted-frame product of the current c0
@@ -440,6 +440,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             a.src_item_polys = L; a.src_item_stride = 2 * n; a.src_div = L; a.load_op = LOAD_RNEG;
             a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.aux_r = c->w->ws_S; a.acc = accp0;
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g;
+            if (c->probe & 1) a.store_op = STORE_PLAIN;  // timing probe: price of the fused c0 epilogue (results invalid)
             k_ntt(a, false, s5);
             if (side) rt_event_record(lane.ev_k5[i & 1], s5);
         }

@@ -313,6 +313,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     if (const char *e = getenv("HHE_GRAPH")) c->use_graphs = atoi(e);
     if (const char *e = getenv("HHE_MACFUSE")) c->mac_fuse = atoi(e);
     if (const char *e = getenv("HHE_SIDE")) c->side_stream = atoi(e);
+    if (const char *e = getenv("HHE_PIPE_PROBE")) c->probe = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
     if (const char *e = getenv("HHE_FC_CHUNK")) c->fc_chunk = (size_t)std::max(0, atoi(e));
     if (const char *e = getenv("HHE_DIGIT_SUB")) c->digit_sub = (size_t)std::max(0, atoi(e));

@@ -53,6 +53,7 @@ struct hhe_ctx {
     int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
     int use_graphs = 1;            // replay the fused matmul loop (1143 launches per layer) as a hipGraph on internal streams
     int side_stream = 0;           // overlap the off-critical-path c0 update (K5) with the next digit transforms
+    int probe = 0;                 // HHE_PIPE_PROBE timing probes (bench only; results invalid when set)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
     size_t fc_chunk = 40;          // items per internal chunk of hhe_fc_row (0 = whole batch)
     size_t digit_sub = 0;          // >0: run the digit transforms + inner product in sub-batches of this many items (T stays cache resident)
