@@ -66,8 +66,11 @@ def main():
     rank, world, local_rank = sh.rank_world()
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sh.init_process_group("nccl")  # RCCL; used for the barrier / time reduction only
+        # RCCL; used for the barrier / time reduction only (HHE_BENCH_BACKEND=gloo: rehearsal of the N>1 path on one GPU)
+        sh.init_process_group(os.environ.get("HHE_BENCH_BACKEND", "nccl"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    if "HHE_BENCH_DEVICE" in os.environ:  # rehearsal only: several ranks on one card
+        local_rank = int(os.environ["HHE_BENCH_DEVICE"])
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
     lib = api.load_library()
@@ -120,7 +123,8 @@ def main():
     sh.barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    el_max, units = sh.reduce_max_sum(elapsed, B * args.steps, device=dev if world > 1 else "cpu")
+    red_dev = dev if (world > 1 and os.environ.get("HHE_BENCH_BACKEND", "nccl") == "nccl") else "cpu"
+    el_max, units = sh.reduce_max_sum(elapsed, B * args.steps, device=red_dev)
     value = units / el_max
 
     # dominant kernel (ntt_pass_kernel) measured by itself with HIP events on the library's stream, in the launch mix
