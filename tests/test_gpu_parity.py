@@ -229,3 +229,45 @@ def test_execution_knobs_are_result_neutral(orc, api, lib, mem, small, monkeypat
     res = mem.to_host(out)
     for b in (0, 2):
         assert (res[b] == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[b, :ncw[b]], b)).all(), knobs
+
+
+def test_config2_full_batch_256(orc, api, lib, mem):
+    """BASELINE config 2 at its full size (256 blocks per GPU: 8 chunks over 2 internal streams, graph replay): item 0 and
+    item 255 against the oracle, every other item through the size-independent linearity property, and a checksum of
+    checksums across the batch."""
+    S = Setup(orc, 15, [60] * 4)
+    O = S.O
+    X = api.Context(S.logn, S.q, S.t, lib=lib)
+    S.load_keys(X)
+    B = 256
+    rng = np.random.default_rng(2)
+    cw = rng.integers(0, S.t, size=(B, 128), dtype=np.uint64)
+    out = mem.empty((B,) + O.ct_shape)
+    X.transcipher(mem.to_dev(S.enc_key), cw, [128] * B, [0] * B, out)
+    res = mem.to_host(out)
+    for i in (0, B - 1):
+        assert (res[i] == O.transcipher_block(S.enc_key, S.rk, S.gk, cw[i], 0)).all()
+    base = O.sub_plain(res[0], O.encode(cw[0]))  # = -KS, common to the batch (block counter 0)
+    for i in range(1, B - 1, 17):
+        assert (res[i] == O.add_plain(base, O.encode(cw[i]))).all()
+    # all items differ only in c0 (add_plain touches c0 only): c1 must be identical across the batch
+    assert (res[:, 1] == res[0, 1]).all()
+
+
+def test_decompose_on_device(orc, api, lib, mem):
+    """BaseCSP::decompose glue (blocks -> mask -> flatten) for two records on the GPU"""
+    S = Setup(orc, 10, [50] * 9, extra_steps=(-128, -256))
+    O = S.O
+    X = api.Context(S.logn, S.q, S.t, lib=lib)
+    S.load_keys(X)
+    pts = [np.array([(7 * i + 3 + s) % 256 for i in range(300)], dtype=np.uint64) for s in range(2)]
+    recs = np.stack([orc.pasta_encrypt(S.t, S.key, p) for p in pts])
+    out = mem.empty((2,) + O.ct_shape)
+    X.decompose(mem.to_dev(S.enc_key), recs, out, mask_last=True)
+    res = mem.to_host(out)
+    for s in range(2):
+        cw, ncw = S.sym_blocks(orc, pts[s])
+        blocks = [O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b) for b in range(3)]
+        blocks[2] = O.mask(blocks[2], np.ones(44, np.uint64))
+        assert (res[s] == O.flatten(np.stack(blocks), S.gk)).all()
+        assert (O.decode(O.decrypt(S.sk, res[s]))[:300] == pts[s]).all()
