@@ -84,6 +84,46 @@ template <bool STRIDED> HD void ntt_pair(const NttArgs &a, const NttGeom &g, int
     gi = ntt_gidx<STRIDED>(g, x, lane);
 }
 
+// load op of the first pass applied to one 16-byte pair
+template <bool FIRST> HD U2 ntt_load_op(const NttArgs &a, const ModDev &m, int poly, U2 v)
+{
+    if (FIRST) {
+        if (a.load_op == LOAD_DIGIT) { if (a.digit_reduce) { v.a = reduce64(v.a, m); v.b = reduce64(v.b, m); } }
+        else if (a.load_op == LOAD_LIFT) {
+            const u64 thr = (a.t + 1) >> 1, inc = m.q - a.t;
+            v.a = (v.a >= thr) ? v.a + inc : v.a;
+            v.b = (v.b >= thr) ? v.b + inc : v.b;
+        } else if (a.load_op == LOAD_RNEG) {
+            const u64 h = a.ks.half_mod[poly % a.L];
+            v.a = submod(reduce64(v.a, m), h, m.q);
+            v.b = submod(reduce64(v.b, m), h, m.q);
+        }
+    }
+    return v;
+}
+// full tiles (every launch with N >= 4096): all NP global loads of a lane are issued before the first LDS write, so
+// a workgroup's load phase costs one memory round trip instead of NP
+template <bool STRIDED, bool INVERSE, int NP>
+HD void ntt_load_full(const NttArgs &a, const NttGeom &g, const ModDev &m, const u64 *src, int tid, u64 *lds)
+{
+    constexpr bool FIRST = (STRIDED != INVERSE);
+    U2 v[NP];
+    int l0[NP], l1[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        int x, lane, gi;
+        ntt_pair<STRIDED>(a, g, tid + k * NTT_THREADS, x, lane, gi, l0[k], l1[k]);
+        if (FIRST && a.load_op == 99) { v[k].a = (u64)(x * 131 + lane); v[k].b = v[k].a + 1; }  // timing probe (no global read)
+        else v[k] = ld2(src + gi);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const U2 w = ntt_load_op<FIRST>(a, m, g.poly, v[k]);
+        lds[l0[k]] = w.a;
+        lds[l1[k]] = w.b;
+    }
+}
+
 template <bool STRIDED, bool INVERSE>
 HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
@@ -96,24 +136,15 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
         src = a.src + (size_t)(g.poly / ip) * a.src_item_stride + (size_t)((g.poly % ip) / a.src_div) * g.n;
     } else src = a.dst + (size_t)g.poly * g.n;
     const int E2 = (g.M * g.C) >> 1;
+    if (E2 == 8 * NTT_THREADS) { ntt_load_full<STRIDED, INVERSE, 8>(a, g, m, src, tid, lds); return; }
+    if (E2 == 4 * NTT_THREADS) { ntt_load_full<STRIDED, INVERSE, 4>(a, g, m, src, tid, lds); return; }
     for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) {
         int x, lane, gi, l0, l1;
         ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
         U2 v;
         if (FIRST && a.load_op == 99) { v.a = (u64)(x * 131 + lane); v.b = v.a + 1; }  // timing probe (no global read)
         else v = ld2(src + gi);
-        if (FIRST) {
-            if (a.load_op == LOAD_DIGIT) { if (a.digit_reduce) { v.a = reduce64(v.a, m); v.b = reduce64(v.b, m); } }
-            else if (a.load_op == LOAD_LIFT) {
-                const u64 thr = (a.t + 1) >> 1, inc = m.q - a.t;
-                v.a = (v.a >= thr) ? v.a + inc : v.a;
-                v.b = (v.b >= thr) ? v.b + inc : v.b;
-            } else if (a.load_op == LOAD_RNEG) {
-                const u64 h = a.ks.half_mod[g.poly % a.L];
-                v.a = submod(reduce64(v.a, m), h, m.q);
-                v.b = submod(reduce64(v.b, m), h, m.q);
-            }
-        }
+        v = ntt_load_op<FIRST>(a, m, g.poly, v);
         lds[l0] = v.a;
         lds[l1] = v.b;
     }
