@@ -216,94 +216,108 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 }
 
 template <bool STRIDED, bool INVERSE>
-HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds)
+HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 *dst, size_t pbase, int e2, const u64 *lds)
 {
     constexpr bool LAST = (STRIDED == INVERSE);
+    const u64 q = m.q, q2 = q << 1;
+    int x, lane, gi, l0, l1;
+    ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
+    u64 v[2] = {lds[l0], lds[l1]};
+    if (a.store_op == 99) { if (v[0] == 0x123456789abcdefULL) dst[gi] = v[0]; return; }  // timing probe (no global write)
+    if (!LAST || (!INVERSE && a.store_op == STORE_LAZY)) { st2(dst + gi, U2{v[0], v[1]}); return; }
+    if (INVERSE) {
+        const bool st = a.store_op == STORE_SCALE_T;
+        for (int k = 0; k < 2; k++) {
+            v[k] = shoup_lazy(v[k], st ? m.ninv_t : m.ninv, st ? m.ninv_t_s : m.ninv_s, q);
+            v[k] -= (v[k] >= q) ? q : 0;
+        }
+        if (a.store_op == STORE_RSP || a.store_op == STORE_RACC) { v[0] = addmod(v[0], a.ks.half, q); v[1] = addmod(v[1], a.ks.half, q); }
+        if (a.store_op == STORE_RACC) {  // poly = (item, k): rounding terms of a leaf key switch, summed per data limb
+            for (int j = 0; j < a.L; j++) {
+                const ModDev &mj = a.mods[j];
+                u64 *ap = a.acc + ((size_t)g.poly * a.L + j) * g.n + gi;
+                U2 ac = ld2(ap);
+                ac.a = addmod(ac.a, submod(a.ks.half_mod[j], reduce64(v[0], mj), mj.q), mj.q);
+                ac.b = addmod(ac.b, submod(a.ks.half_mod[j], reduce64(v[1], mj), mj.q), mj.q);
+                st2(ap, ac);
+            }
+            return;
+        }
+        else if (a.store_op == STORE_KS1) {
+            const int j = g.poly % a.L;
+            const size_t item = g.poly / a.L;
+            const U2 r = ld2(a.aux_r + (item * 2 + 1) * g.n + gi);
+            const u64 rr[2] = {r.a, r.b};
+            for (int k = 0; k < 2; k++) {
+                u64 o = addmod(submod(v[k], reduce64(rr[k], m), q), a.ks.half_mod[j], q);
+                o = shoup_mul(o, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
+                u32 idx = (u32)(gi + k);
+                if (a.gal_elt) {
+                    const u64 raw = (u64)(gi + k) * a.gal_elt;
+                    idx = (u32)(raw & (g.n - 1));
+                    if ((raw >> a.logn) & 1) o = negmod(o, q);
+                }
+                a.aux_out[pbase + idx] = o;
+            }
+            return;
+        }
+    } else {
+        for (int k = 0; k < 2; k++) {
+            v[k] -= (v[k] >= q2) ? q2 : 0;
+            v[k] -= (v[k] >= q) ? q : 0;
+        }
+        if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
+            const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
+            const U2 d = ld2(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);
+            v[0] = mulmod(v[0], d.a, m);
+            v[1] = mulmod(v[1], d.b, m);
+            if (a.store_op == STORE_MAC) {
+                U2 acc = ld2(a.acc + pbase + gi);
+                acc.a = addmod(acc.a, v[0], q);
+                acc.b = addmod(acc.b, v[1], q);
+                st2(a.acc + pbase + gi, acc);
+                return;
+            }
+        } else if (a.store_op == STORE_KS0) {
+            const int j = g.poly % a.L;
+            const size_t item = g.poly / a.L;
+            const U2 d = ld2(a.mul_ptrs[item] + a.mul_shift + (size_t)j * g.n + gi);
+            const U2 s0 = ld2(a.aux_r + ((item * 2 + 0) * a.K + j) * g.n + gi);
+            U2 acc = ld2(a.acc + pbase + gi);
+            const u64 g0 = a.aux_in[pbase + ntt_perm_index((u32)gi, a.logn, a.gal_elt)];
+            const u64 g1 = a.aux_in[pbase + ntt_perm_index((u32)gi + 1, a.logn, a.gal_elt)];
+            acc.a = addmod(acc.a, mulmod(g0, d.a, m), q);
+            acc.b = addmod(acc.b, mulmod(g1, d.b, m), q);
+            st2(a.acc + pbase + gi, acc);
+            U2 o;
+            o.a = addmod(g0, shoup_mul(submod(s0.a, v[0], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
+            o.b = addmod(g1, shoup_mul(submod(s0.b, v[1], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
+            st2(a.aux_out + pbase + gi, o);
+            return;
+        }
+    }
+    st2(dst + gi, U2{v[0], v[1]});
+}
+
+template <bool STRIDED, bool INVERSE>
+HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds)
+{
     const NttGeom g = ntt_geom(a, bx, by);
     const ModDev &m = a.mods[g.mod_index];
-    const u64 q = m.q, q2 = q << 1;
     u64 *dst = a.dst + (size_t)g.poly * g.n;
     const size_t pbase = (size_t)g.poly * g.n;
     const int E2 = (g.M * g.C) >> 1;
-    for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) {
-        int x, lane, gi, l0, l1;
-        ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
-        u64 v[2] = {lds[l0], lds[l1]};
-        if (a.store_op == 99) { if (v[0] == 0x123456789abcdefULL) dst[gi] = v[0]; continue; }  // timing probe (no global write)
-        if (!LAST || (!INVERSE && a.store_op == STORE_LAZY)) { st2(dst + gi, U2{v[0], v[1]}); continue; }
-        if (INVERSE) {
-            const bool st = a.store_op == STORE_SCALE_T;
-            for (int k = 0; k < 2; k++) {
-                v[k] = shoup_lazy(v[k], st ? m.ninv_t : m.ninv, st ? m.ninv_t_s : m.ninv_s, q);
-                v[k] -= (v[k] >= q) ? q : 0;
-            }
-            if (a.store_op == STORE_RSP || a.store_op == STORE_RACC) { v[0] = addmod(v[0], a.ks.half, q); v[1] = addmod(v[1], a.ks.half, q); }
-            if (a.store_op == STORE_RACC) {  // poly = (item, k): rounding terms of a leaf key switch, summed per data limb
-                for (int j = 0; j < a.L; j++) {
-                    const ModDev &mj = a.mods[j];
-                    u64 *ap = a.acc + ((size_t)g.poly * a.L + j) * g.n + gi;
-                    U2 ac = ld2(ap);
-                    ac.a = addmod(ac.a, submod(a.ks.half_mod[j], reduce64(v[0], mj), mj.q), mj.q);
-                    ac.b = addmod(ac.b, submod(a.ks.half_mod[j], reduce64(v[1], mj), mj.q), mj.q);
-                    st2(ap, ac);
-                }
-                continue;
-            }
-            else if (a.store_op == STORE_KS1) {
-                const int j = g.poly % a.L;
-                const size_t item = g.poly / a.L;
-                const U2 r = ld2(a.aux_r + (item * 2 + 1) * g.n + gi);
-                const u64 rr[2] = {r.a, r.b};
-                for (int k = 0; k < 2; k++) {
-                    u64 o = addmod(submod(v[k], reduce64(rr[k], m), q), a.ks.half_mod[j], q);
-                    o = shoup_mul(o, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
-                    u32 idx = (u32)(gi + k);
-                    if (a.gal_elt) {
-                        const u64 raw = (u64)(gi + k) * a.gal_elt;
-                        idx = (u32)(raw & (g.n - 1));
-                        if ((raw >> a.logn) & 1) o = negmod(o, q);
-                    }
-                    a.aux_out[pbase + idx] = o;
-                }
-                continue;
-            }
-        } else {
-            for (int k = 0; k < 2; k++) {
-                v[k] -= (v[k] >= q2) ? q2 : 0;
-                v[k] -= (v[k] >= q) ? q : 0;
-            }
-            if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
-                const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
-                const U2 d = ld2(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);
-                v[0] = mulmod(v[0], d.a, m);
-                v[1] = mulmod(v[1], d.b, m);
-                if (a.store_op == STORE_MAC) {
-                    U2 acc = ld2(a.acc + pbase + gi);
-                    acc.a = addmod(acc.a, v[0], q);
-                    acc.b = addmod(acc.b, v[1], q);
-                    st2(a.acc + pbase + gi, acc);
-                    continue;
-                }
-            } else if (a.store_op == STORE_KS0) {
-                const int j = g.poly % a.L;
-                const size_t item = g.poly / a.L;
-                const U2 d = ld2(a.mul_ptrs[item] + a.mul_shift + (size_t)j * g.n + gi);
-                const U2 s0 = ld2(a.aux_r + ((item * 2 + 0) * a.K + j) * g.n + gi);
-                U2 acc = ld2(a.acc + pbase + gi);
-                const u64 g0 = a.aux_in[pbase + ntt_perm_index((u32)gi, a.logn, a.gal_elt)];
-                const u64 g1 = a.aux_in[pbase + ntt_perm_index((u32)gi + 1, a.logn, a.gal_elt)];
-                acc.a = addmod(acc.a, mulmod(g0, d.a, m), q);
-                acc.b = addmod(acc.b, mulmod(g1, d.b, m), q);
-                st2(a.acc + pbase + gi, acc);
-                U2 o;
-                o.a = addmod(g0, shoup_mul(submod(s0.a, v[0], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
-                o.b = addmod(g1, shoup_mul(submod(s0.b, v[1], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
-                st2(a.aux_out + pbase + gi, o);
-                continue;
-            }
-        }
-        st2(dst + gi, U2{v[0], v[1]});
+    if (E2 == 8 * NTT_THREADS) {  // full tiles: constant trip count, unrolled
+#pragma unroll
+        for (int k = 0; k < 8; k++) ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, tid + k * NTT_THREADS, lds);
+        return;
     }
+    if (E2 == 4 * NTT_THREADS) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, tid + k * NTT_THREADS, lds);
+        return;
+    }
+    for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, e2, lds);
 }
 
 // ------------------------------------------------------------------ element-wise
