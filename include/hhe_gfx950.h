@@ -136,6 +136,20 @@ int hhe_fc_row(hhe_ctx *c, const uint64_t *vi_dptr, const uint64_t *w_dptr, size
  * mats [4][2][128][128], rcs [4][2][128] */
 int hhe_pasta3_block_randomness(uint64_t t, uint64_t block_index, uint64_t *mats_hptr, uint64_t *rcs_hptr);
 
+/* ---- client / analyst ends ---- */
+/* pasta::Pasta::keystream (src/pasta/pasta_3_plain.cpp:156-178) for block counters first_block .. first_block+nblocks-1
+ * (nonce 123456789) under the 256-word secret key key_hptr (words < t): ks_dptr [nblocks][128] device. */
+int hhe_pasta3_plain_keystream(hhe_ctx *c, const uint64_t *key_hptr, uint64_t first_block, size_t nblocks, uint64_t *ks_dptr);
+/* pasta::PASTA::encrypt / decrypt (src/pasta/pasta_3_plain.cpp:9-46) over S records of nwords words each (device,
+ * [S][nwords]); every record starts at block counter 0, as each PASTA::encrypt call does.  in == out is allowed. */
+int hhe_pasta3_plain_crypt(hhe_ctx *c, const uint64_t *key_hptr, const uint64_t *in_dptr, size_t S, size_t nwords,
+                           int decrypt, uint64_t *out_dptr);
+/* Decryptor::decrypt + BatchEncoder::decode (seal/decryptor.h:70, seal/batchencoder.h:282) as used by
+ * sealhelper::decrypting / Analyst::decrypt_result (src/util/sealhelper.cpp:252-266): B size-2 data-level
+ * ciphertexts [B][2][L][N] -> slot values [B][N] (unsigned, < t; the signed view of decode_int64 is v > t/2 ? v - t : v).
+ * sk_hptr: the secret key polynomial at the key level, NTT form [K][N] (SecretKey::data().data()). */
+int hhe_decrypt(hhe_ctx *c, const uint64_t *sk_hptr, const uint64_t *ct_dptr, size_t B, uint64_t *vals_dptr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,7 @@ _SYMBOLS = [
     "hhe_encode", "hhe_add", "hhe_negate", "hhe_add_plain", "hhe_multiply_plain", "hhe_apply_galois",
     "hhe_rotate_rows", "hhe_rotate_columns", "hhe_multiply", "hhe_relinearize",
     "hhe_pasta3_transcipher", "hhe_pasta3_clear_block_cache", "hhe_mask", "hhe_flatten", "hhe_fc_row", "hhe_decompose",
-    "hhe_pasta3_block_randomness",
+    "hhe_pasta3_block_randomness", "hhe_pasta3_plain_keystream", "hhe_pasta3_plain_crypt", "hhe_decrypt",
 ]
 
 
@@ -207,6 +207,27 @@ class Context:
     def fc_row(self, vi, w, W, n_inputs, out, B, relin_slot=0, default_galois_only=True):
         self._chk(self.lib.hhe_fc_row(self.h, _ptr(vi), _ptr(w), C.c_size_t(W), C.c_size_t(n_inputs), C.c_int(relin_slot),
                                       C.c_int(int(default_galois_only)), _ptr(out), C.c_size_t(B)))
+
+
+    # ---- client / analyst ends ----
+    def plain_keystream(self, key, first_block, nblocks, ks_out):
+        """key: host uint64 [256]; ks_out device [nblocks][128]"""
+        key = np.ascontiguousarray(key, dtype=np.uint64)
+        assert key.shape == (2 * PASTA_T,)
+        self._chk(self.lib.hhe_pasta3_plain_keystream(self.h, _ptr(key), C.c_uint64(first_block), C.c_size_t(nblocks), _ptr(ks_out)))
+
+    def plain_crypt(self, key, records, S, nwords, out, decrypt=False):
+        """records/out: device uint64 [S][nwords]"""
+        key = np.ascontiguousarray(key, dtype=np.uint64)
+        assert key.shape == (2 * PASTA_T,)
+        self._chk(self.lib.hhe_pasta3_plain_crypt(self.h, _ptr(key), _ptr(records), C.c_size_t(S), C.c_size_t(nwords),
+                                                  C.c_int(int(decrypt)), _ptr(out)))
+
+    def decrypt(self, sk, ct, B, vals_out):
+        """sk: host uint64 [K][N] (NTT form, key level); ct device [B][2][L][N]; vals_out device [B][N]"""
+        sk = np.ascontiguousarray(sk, dtype=np.uint64)
+        assert sk.size >= self.L * self.n
+        self._chk(self.lib.hhe_decrypt(self.h, _ptr(sk), _ptr(ct), C.c_size_t(B), _ptr(vals_out)))
 
 
 def bfv_default_coeff_modulus(n, lib=None):

@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libhhe_gfx950.so")
-SOURCES = ["hhe_kernels.hip", "hhe_api.cpp", "hhe_context.cpp", "hhe_pasta_public.cpp"]
+SOURCES = ["hhe_kernels.hip", "hhe_api.cpp", "hhe_context.cpp", "hhe_pasta_public.cpp", "hhe_client.cpp"]
 HEADERS = ["hhe_common.h", "hhe_modarith.h", "hhe_kernel_bodies.h", "hhe_launch.h", "hhe_internal.h"]
 
 

@@ -258,3 +258,28 @@ void k_bsgs_diag(const BsgsDiagArgs &a, rt_stream s) { LAUNCH1D(bsgs_diag_kernel
 void k_behz_extend(const BehzExtendArgs &a, rt_stream s) { LAUNCH1D(behz_extend_kernel, (size_t)a.P << a.logn, s, a); }
 void k_tensor(const TensorArgs &a, rt_stream s) { LAUNCH1D(tensor_kernel, ((size_t)a.B * a.limbs) << a.logn, s, a); }
 void k_behz_floor(const BehzFloorArgs &a, rt_stream s) { LAUNCH1D(behz_floor_kernel, (size_t)a.P << a.logn, s, a); }
+
+// ---------------------------------------------------------------- plain PASTA-3 (client / analyst side)
+__global__ void __launch_bounds__(64) pasta_xof_kernel(PastaXofArgs a) { pasta_xof_body(a, (size_t)blockIdx.x * 64 + threadIdx.x); }
+__global__ void __launch_bounds__(PASTA_PLAIN_THREADS) pasta_plain_kernel(PastaPlainArgs a)
+{
+    __shared__ u64 lds[PASTA_PLAIN_LDS];
+    pasta_plain_schedule([&](int kind, int layer, int i) {
+        pasta_plain_phase(a, (int)blockIdx.x, (int)threadIdx.x, layer, kind, i, lds);
+        __syncthreads();
+    });
+}
+__global__ void __launch_bounds__(ELT_THREADS) pasta_crypt_kernel(PastaCryptArgs a) { pasta_crypt_body(a, GID); }
+void k_pasta_xof(const PastaXofArgs &a, rt_stream s)
+{
+    if (a.nblocks > 0) hipLaunchKernelGGL(pasta_xof_kernel, dim3((a.nblocks + 63) / 64), dim3(64), 0, (hipStream_t)s, a);
+}
+void k_pasta_plain(const PastaPlainArgs &a, rt_stream s)
+{
+    if (a.nblocks > 0) hipLaunchKernelGGL(pasta_plain_kernel, dim3(a.nblocks), dim3(PASTA_PLAIN_THREADS), 0, (hipStream_t)s, a);
+}
+void k_pasta_crypt(const PastaCryptArgs &a, rt_stream s) { LAUNCH1D(pasta_crypt_kernel, a.S * a.nwords, s, a); }
+__global__ void __launch_bounds__(ELT_THREADS) decrypt_round_kernel(DecryptArgs a) { decrypt_round_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) decode_gather_kernel(DecodeArgs a) { decode_gather_body(a, GID); }
+void k_decrypt_round(const DecryptArgs &a, rt_stream s) { LAUNCH1D(decrypt_round_kernel, a.B << a.logn, s, a); }
+void k_decode_gather(const DecodeArgs &a, rt_stream s) { LAUNCH1D(decode_gather_kernel, a.B << a.logn, s, a); }

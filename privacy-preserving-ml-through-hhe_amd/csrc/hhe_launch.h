@@ -3,6 +3,7 @@
 // the index arithmetic only, by tests/emu/hhe_launch_emu.cpp.
 #pragma once
 #include "hhe_common.h"
+#include "hhe_client_bodies.h"
 
 typedef void *rt_stream;
 
@@ -48,6 +49,12 @@ void k_bsgs_diag(const BsgsDiagArgs &a, rt_stream s);
 void k_behz_extend(const BehzExtendArgs &a, rt_stream s);
 void k_tensor(const TensorArgs &a, rt_stream s);
 void k_behz_floor(const BehzFloorArgs &a, rt_stream s);
+// plain PASTA-3 (client side): XOF field elements, keystream blocks, record encryption / decryption
+void k_pasta_xof(const PastaXofArgs &a, rt_stream s);
+void k_pasta_plain(const PastaPlainArgs &a, rt_stream s);
+void k_pasta_crypt(const PastaCryptArgs &a, rt_stream s);
+void k_decrypt_round(const DecryptArgs &a, rt_stream s);
+void k_decode_gather(const DecodeArgs &a, rt_stream s);
 
 // split of logn into the two pass sizes (strided pass n1, row pass n2)
 inline void ntt_split(int logn, int &n1, int &n2) { n1 = logn / 2; n2 = logn - n1; }

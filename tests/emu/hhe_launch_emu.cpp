@@ -180,3 +180,18 @@ void k_bsgs_diag(const BsgsDiagArgs &a, rt_stream) { LOOP((size_t)(PASTA_R + 1) 
 void k_behz_extend(const BehzExtendArgs &a, rt_stream) { LOOP((size_t)a.P << a.logn, behz_extend_body(a, (size_t)g)); }
 void k_tensor(const TensorArgs &a, rt_stream) { LOOP(((size_t)a.B * a.limbs) << a.logn, tensor_body(a, (size_t)g)); }
 void k_behz_floor(const BehzFloorArgs &a, rt_stream) { LOOP((size_t)a.P << a.logn, behz_floor_body(a, (size_t)g)); }
+
+void k_pasta_xof(const PastaXofArgs &a, rt_stream) { LOOP(a.nblocks, pasta_xof_body(a, (size_t)g)); }
+void k_pasta_plain(const PastaPlainArgs &a, rt_stream)
+{
+#pragma omp parallel for
+    for (int blk = 0; blk < a.nblocks; blk++) {
+        std::vector<u64> lds(PASTA_PLAIN_LDS, 0);
+        pasta_plain_schedule([&](int kind, int layer, int i) {
+            for (int t = 0; t < PASTA_PLAIN_THREADS; t++) pasta_plain_phase(a, blk, t, layer, kind, i, lds.data());
+        });
+    }
+}
+void k_pasta_crypt(const PastaCryptArgs &a, rt_stream) { LOOP(a.S * a.nwords, pasta_crypt_body(a, (size_t)g)); }
+void k_decrypt_round(const DecryptArgs &a, rt_stream) { LOOP(a.B << a.logn, decrypt_round_body(a, (size_t)g)); }
+void k_decode_gather(const DecodeArgs &a, rt_stream) { LOOP(a.B << a.logn, decode_gather_body(a, (size_t)g)); }

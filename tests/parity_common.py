@@ -139,3 +139,59 @@ def check_transcipher(X, S, orc, mem, pt, block_ids=None, check_decrypt=True, or
             dec = O.decode(O.decrypt(S.sk, res[b]))[:ncw[b]]
             assert (dec == np.asarray(pt[b * 128:b * 128 + ncw[b]], dtype=np.uint64)).all()
     return res
+
+
+def golden_key(t):
+    return np.array([(i * 2654435761 + 12345) % t for i in range(256)], dtype=np.uint64)
+
+
+def check_plain_cipher_golden(X, orc, mem, golden):
+    """Client-side plain PASTA-3 on the device vs the vectors the reference's own pasta_3_plain.cpp produced
+    (tests/golden/pasta_plain.json) and vs the oracle for block counters the fixture does not hold."""
+    t = X.t
+    key = golden_key(t)
+    hit = 0
+    for c in golden["randomness"]:
+        if c["t"] != t:
+            continue
+        ks = mem.empty((1, 128))
+        X.plain_keystream(key, c["block"], 1, ks)
+        assert [int(v) for v in mem.to_host(ks)[0]] == c["keystream"]
+        hit += 1
+    assert hit, "no golden keystream for this modulus"
+    # a run of consecutive counters in one launch, each block against the oracle
+    nb = 5
+    ks = mem.empty((nb, 128))
+    X.plain_keystream(key, 3, nb, ks)
+    got = mem.to_host(ks)
+    for b in range(nb):
+        assert (got[b] == orc.pasta_keystream(t, key, 3 + b)).all()
+    for e in golden["encrypt"]:
+        if e["t"] != t:
+            continue
+        n = e["n"]
+        S = 3  # every record restarts at counter 0: identical ciphertext rows for identical plaintext rows
+        pt = np.tile(np.array([(7 * i + 3) % 256 for i in range(n)], dtype=np.uint64), (S, 1))
+        d_in, d_out = mem.to_dev(pt), mem.empty((S, n))
+        X.plain_crypt(key, d_in, S, n, d_out)
+        ct = mem.to_host(d_out)
+        for s in range(S):
+            assert [int(v) for v in ct[s]] == e["ct"]
+        X.plain_crypt(key, d_out, S, n, d_out, decrypt=True)  # in place
+        assert (mem.to_host(d_out) == pt).all()
+
+
+def check_decrypt(X, S, mem, B=3, seed=0):
+    """Batched Decryptor::decrypt + BatchEncoder::decode vs the oracle, on fresh and on evaluated ciphertexts."""
+    O = S.O
+    rng = np.random.default_rng(seed)
+    vals = rng.integers(0, O.t, (B, O.n), dtype=np.uint64)
+    cts = np.stack([O.encrypt(S.pk, O.encode(vals[b]), 30 + b) for b in range(B)])
+    # one evaluated ciphertext (rotation: key-switch noise) so that the rounding path is not trivial
+    cts[B - 1] = O.rotate_rows(cts[B - 1], -1, S.gk)[0]
+    out = mem.empty((B, O.n))
+    X.decrypt(S.sk, mem.to_dev(cts), B, out)
+    got = mem.to_host(out)
+    for b in range(B):
+        assert (got[b] == O.decode(O.decrypt(S.sk, cts[b]))).all()
+    assert (got[0] == vals[0]).all()

@@ -271,3 +271,53 @@ def test_decompose_on_device(orc, api, lib, mem):
         blocks[2] = O.mask(blocks[2], np.ones(44, np.uint64))
         assert (res[s] == O.flatten(np.stack(blocks), S.gk)).all()
         assert (O.decode(O.decrypt(S.sk, res[s]))[:300] == pts[s]).all()
+
+
+@pytest.mark.parametrize("t,logn,bits", [(65537, 10, [50, 50]), (8088322049, 12, [55, 55]), (1096486890805657601, 10, [60, 60])])
+def test_client_plain_pasta_matches_reference_built_golden(orc, api, lib, mem, t, logn, bits):
+    """SURVEY 8f-4 on the GPU: PASTA::encrypt / decrypt / keystream kernels vs vectors from the reference's pasta_3_plain.cpp"""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pasta_plain.json")))
+    X = api.Context(logn, orc.coeff_modulus_create(1 << logn, bits), t, lib=lib)
+    pc.check_plain_cipher_golden(X, orc, mem, g)
+
+
+def test_client_bulk_keystream_many_counters(orc, api, lib, mem, small):
+    """one launch over 1000 block counters: spot checks against the oracle + all blocks distinct"""
+    X = api.Context(small.logn, small.q, small.t, lib=lib)
+    key = pc.golden_key(small.t)
+    nb = 1000
+    ks = mem.empty((nb, 128))
+    X.plain_keystream(key, 7, nb, ks)
+    got = mem.to_host(ks)
+    for b in (0, 1, 63, 64, 511, 999):
+        assert (got[b] == orc.pasta_keystream(small.t, key, 7 + b)).all()
+    assert len({row.tobytes() for row in got}) == nb
+    assert int(got.max()) < small.t
+
+
+def test_analyst_batched_decrypt(orc, api, lib, mem, small):
+    X = api.Context(small.logn, small.q, small.t, lib=lib)
+    small.load_keys(X)
+    pc.check_decrypt(X, small, mem, B=5)
+
+
+def test_end_to_end_client_encrypt_csp_transcipher_analyst_decrypt(orc, api, lib, mem):
+    """the whole protocol on the device: PASTA-encrypt (client) -> decompose (CSP) -> decrypt (analyst) returns the input"""
+    S = Setup(orc, 10, [50] * 9, extra_steps=(-128, -256))
+    X = api.Context(S.logn, S.q, S.t, lib=lib)
+    S.load_keys(X)
+    rng = np.random.default_rng(11)
+    pts = rng.integers(0, 4, (2, 300), dtype=np.uint64)
+    d_ct = mem.empty((2, 300))
+    X.plain_crypt(S.key, mem.to_dev(pts), 2, 300, d_ct)
+    recs = mem.to_host(d_ct)
+    for s in range(2):
+        assert (recs[s] == orc.pasta_encrypt(S.t, S.key, pts[s])).all()
+    out = mem.empty((2,) + S.O.ct_shape)
+    X.decompose(mem.to_dev(S.enc_key), recs, out, mask_last=True)
+    vals = mem.empty((2, S.O.n))
+    X.decrypt(S.sk, out, 2, vals)
+    got = mem.to_host(vals)
+    assert (got[:, :300] == pts).all() and not got[:, 300:S.O.n // 2].any()

@@ -276,3 +276,25 @@ def test_edge_cases_single_word_block_and_large_block_counter(orc, api, emu_lib,
         X.transcipher(mem.to_dev(small.enc_key), np.zeros((0, 128), np.uint64), [], [], out)
     with pytest.raises(api.HheError):
         X.transcipher(mem.to_dev(small.enc_key), cw, [129, 128], counters, out)  # more than 128 words in a block
+
+
+@pytest.mark.parametrize("t,logn,bits", [(65537, 10, [50, 50]), (8088322049, 10, [55, 55]), (1096486890805657601, 10, [60, 60])])
+def test_client_plain_pasta_matches_reference_built_golden(orc, api, emu_lib, mem, t, logn, bits):
+    """SURVEY 8f-4: device PASTA::encrypt/decrypt/keystream vs vectors produced by the reference's own pasta_3_plain.cpp."""
+    g = json.load(open(os.path.join(HERE, "golden", "pasta_plain.json")))
+    X = api.Context(logn, orc.coeff_modulus_create(1 << logn, bits), t, lib=emu_lib)
+    pc.check_plain_cipher_golden(X, orc, mem, g)
+
+
+def test_client_plain_pasta_rejects_key_words_above_modulus(api, emu_lib, mem, small):
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    key = np.full(256, small.t, np.uint64)
+    with pytest.raises(api.HheError) as e:
+        X.plain_keystream(key, 0, 1, mem.empty((1, 128)))
+    assert e.value.code == api.ERR_INVALID
+
+
+def test_analyst_batched_decrypt_matches_oracle(orc, api, emu_lib, mem, small):
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    small.load_keys(X)
+    pc.check_decrypt(X, small, mem)
