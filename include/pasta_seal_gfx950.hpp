@@ -5,6 +5,8 @@
 //   pasta::SEALZpCipher   src/pasta/SEAL_Cipher.h:11-129   (get_plain_size, mask, flatten, activate_bsgs, ...)
 //   pasta::PASTA_SEAL     src/pasta/pasta_3_seal.h:8-54    (HE_decrypt, decomposition, add_gk_indices, ...)
 //   sealhelper::packed_enc_multiply / encrypted_vec_sum   src/util/sealhelper.h:84-129
+//   pasta::PASTA          src/pasta/pasta_3_plain.h:17-30  (client side: encrypt / decrypt)
+//   sealhelper::decrypting                                 src/util/sealhelper.cpp:252-266 (analyst side)
 // The reference passes seal:: objects; SEAL is not linked here, so the boundary types below are plain
 // word containers with SEAL's in-memory layouts (what Ciphertext::data(), KSwitchKeys::data() hold).
 // INTEGRATION.md shows the 1:1 conversion a SEAL-linking caller adds.  Errors surface as the C++
@@ -262,9 +264,64 @@ private:
     size_t slots, halfslots;
 };
 
+// pasta::PASTA (src/pasta/pasta_3_plain.h:17-30; base ZpCipher src/pasta/Cipher.h:20-58): the client's symmetric
+// cipher, evaluated by the device kernels.  Differs from the reference ctor only by the context handle in front.
+class PASTA {
+public:
+    PASTA(std::shared_ptr<HheContext> con, std::vector<uint64_t> secret_key, uint64_t modulus)
+        : context(std::move(con)), secret_key(std::move(secret_key)), modulus(modulus), params(PASTA_PARAMS)
+    {
+        if (this->secret_key.size() != params.key_size) throw std::runtime_error("Invalid Key length");  // Cipher.h:30-31
+        if (modulus != context->plain_modulus()) throw std::invalid_argument("PASTA modulus differs from the plain modulus of the context");
+    }
+    virtual ~PASTA() = default;
+    virtual std::string get_cipher_name() const { return "PASTA (n=128,r=3)"; }
+    size_t get_key_size() const { return params.key_size; }
+    size_t get_plain_size() const { return params.plain_size; }
+    size_t get_cipher_size() const { return params.cipher_size; }
+    virtual std::vector<uint64_t> encrypt(std::vector<uint64_t> plaintext) const { return crypt(std::move(plaintext), 0); }
+    virtual std::vector<uint64_t> decrypt(std::vector<uint64_t> ciphertext) const { return crypt(std::move(ciphertext), 1); }
+
+private:
+    std::vector<uint64_t> crypt(std::vector<uint64_t> v, int dec) const
+    {
+        if (v.empty()) return v;
+        hhe_ctx *h = context->handle();
+        detail::DevBuf d(v.size() * 8);
+        detail::check(hhe_copy_h2d(h, d.p, v.data(), v.size() * 8));
+        detail::check(hhe_pasta3_plain_crypt(h, secret_key.data(), d.u64(), 1, v.size(), dec, d.u64()));
+        detail::check(hhe_copy_d2h(h, v.data(), d.p, v.size() * 8));
+        return v;
+    }
+    std::shared_ptr<HheContext> context;
+    std::vector<uint64_t> secret_key;
+    uint64_t modulus;
+    ZpCipherParams params;
+};
+
 }  // namespace pasta
 
 namespace sealhelper {
+// sealhelper::decrypting (src/util/sealhelper.cpp:252-266): Decryptor::decrypt + BatchEncoder::decode into signed values
+// (SEAL: slot value v > (t+1)/2 reads as v - t), first `size` slots.  he_sk.words: SecretKey::data() [K][N], NTT form.
+inline std::vector<int64_t> decrypting(const pasta::Ciphertext &enc_input, const pasta::SecretKey &he_sk, pasta::HheContext &ctx,
+                                       size_t size)
+{
+    const size_t w = ctx.ct_words(), n = ctx.poly_modulus_degree();
+    if (enc_input.words.size() != w || he_sk.words.size() < ctx.data_limbs() * n || size > n)
+        throw std::invalid_argument("decrypting: ciphertext / secret key do not match the context");
+    pasta::detail::DevBuf c(w * 8), v(n * 8);
+    hhe_ctx *h = ctx.handle();
+    pasta::detail::check(hhe_copy_h2d(h, c.p, enc_input.words.data(), w * 8));
+    pasta::detail::check(hhe_decrypt(h, he_sk.words.data(), c.u64(), 1, v.u64()));
+    std::vector<uint64_t> u(n);
+    pasta::detail::check(hhe_copy_d2h(h, u.data(), v.p, n * 8));
+    const uint64_t t = ctx.plain_modulus(), half = (t + 1) >> 1;
+    std::vector<int64_t> out(size);
+    for (size_t i = 0; i < size; i++) out[i] = u[i] > half ? (int64_t)u[i] - (int64_t)t : (int64_t)u[i];
+    return out;
+}
+
 // packed_enc_multiply + relinearize + encrypted_vec_sum for one weight row (sealhelper.cpp:268-274,379-392; CSP.cpp:306)
 inline void fc_row(pasta::HheContext &ctx, const pasta::Ciphertext &vi, const pasta::Ciphertext &w_row, size_t vec_size,
                    pasta::Ciphertext &destination)

@@ -29,6 +29,9 @@ int main(int argc, char **argv)
     }
     pasta::Ciphertext enc_key{read_words(f, ctw), 2};
     auto record = read_words(f, hdr[4]);
+    pasta::SecretKey he_sk{read_words(f, (size_t)K * n)};
+    auto sym_key = read_words(f, 256);
+    auto plain_record = read_words(f, hdr[4]);
     fclose(f);
     try {
         auto ctx = std::make_shared<pasta::HheContext>(logn, q, hdr[2], 0);
@@ -52,7 +55,21 @@ int main(int argc, char **argv)
         fwrite(sq.words.data(), 8, sq.words.size(), o);
         fwrite(prod.words.data(), 8, prod.words.size(), o);
         fwrite(sum.words.data(), 8, sum.words.size(), o);
+        // client and analyst ends (User.cpp / Analyst.cpp): PASTA::encrypt, PASTA::decrypt, sealhelper::decrypting
+        pasta::PASTA sym(ctx, sym_key, hdr[2]);
+        auto sym_ct = sym.encrypt(plain_record);
+        auto sym_back = sym.decrypt(sym_ct);
+        fwrite(sym_ct.data(), 8, sym_ct.size(), o);
+        fwrite(sym_back.data(), 8, sym_back.size(), o);
+        if (hdr[5]) {
+            pasta::Ciphertext flat;
+            HHE.flatten(blocks, flat);
+            auto dec = sealhelper::decrypting(flat, he_sk, *ctx, 256);
+            fwrite(dec.data(), 8, dec.size(), o);
+        }
         fclose(o);
+        try { pasta::PASTA bad(ctx, std::vector<uint64_t>(255, 1), hdr[2]); printf("NO THROW\n"); return 3; }
+        catch (const std::runtime_error &e) { printf("throws: %s\n", e.what()); }
         // error behaviour: a context without Galois keys must throw like SEAL does
         pasta::PASTA_SEAL bare(std::make_shared<pasta::HheContext>(logn, q, hdr[2], 0), {}, {}, rk, {});
         try { bare.decomposition(record, {enc_key}); printf("NO THROW\n"); return 3; }

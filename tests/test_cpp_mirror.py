@@ -27,6 +27,9 @@ def _run(orc, tmp_path, libdir, libname, extra_env=None):
             k.tofile(f)
         S.enc_key.tofile(f)
         record.tofile(f)
+        np.ascontiguousarray(S.sk, dtype=np.uint64).tofile(f)
+        S.key.tofile(f)
+        np.asarray(pt, dtype=np.uint64).tofile(f)
     exe = tmp_path / "mirror"
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "mirror_main.cpp"), "-L" + libdir, "-l" + libname,
@@ -45,7 +48,13 @@ def _run(orc, tmp_path, libdir, libname, extra_env=None):
     cts = words[1:base].reshape(nb + 1, *O.ct_shape)
     sq = words[base:base + ctw].reshape(O.ct_shape)
     prod = words[base + ctw:base + ctw + ctw // 2 * 3].reshape(3, O.L, O.n)
-    ssum = words[base + ctw + ctw // 2 * 3:].reshape(O.ct_shape)
+    o2 = base + ctw + ctw // 2 * 3
+    ssum = words[o2:o2 + ctw].reshape(O.ct_shape)
+    sym_ct, sym_back = words[o2 + ctw:o2 + ctw + len(pt)], words[o2 + ctw + len(pt):o2 + ctw + 2 * len(pt)]
+    dec_i64 = words[o2 + ctw + 2 * len(pt):].view(np.int64)
+    assert (sym_ct == record).all() and (sym_back == np.asarray(pt, dtype=np.uint64)).all()   # pasta::PASTA encrypt / decrypt
+    assert "throws: Invalid Key length" in r.stdout
+    assert len(dec_i64) == 256 and (dec_i64 == np.asarray(pt[:256], dtype=np.int64)).all()    # sealhelper::decrypting
     cw, ncw = S.sym_blocks(orc, pt)
     refs = [O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b) for b in range(nb)]
     for b in range(nb):
