@@ -25,8 +25,8 @@ struct ModDev {
     u64 r_lo, r_hi;        // floor(2^128 / q)
     u64 ninv, ninv_s;      // N^-1 mod q and its Shoup quotient
     u64 ninv_t, ninv_t_s;  // N^-1 * t mod q (INTT fused with the BEHZ "times t")
-    const u64 *w, *ws;     // psi^bitrev(k), Shoup quotients          [N]
-    const u64 *iw, *iws;   // inverse of the same entries             [N]
+    const u64 *w, *ws;     // psi^bitrev(k), Shoup quotients [N] each (forward rounds: two 8-byte loads keep the 128-VGPR budget spill-free)
+    const u64 *iw;         // [N][2]: inverse powers interleaved with their Shoup quotients (inverse rounds: one 16-byte load, measured 3 % faster)
 };
 
 // Modulus indices inside ModDev[]: 0..K-1 coefficient primes (K-1 = special),
@@ -66,6 +66,7 @@ struct NttArgs {
     size_t src_item_stride;  // words between items in src
     int load_op, store_op;
     int probe;         // timing probes (tools/ntt_micro.py): bit 2 = skip the butterflies
+    int lazy8;         // every modulus of the launch is below 2^60: forward butterflies correct X once per register round ([0,16q) range)
     int digit_reduce;  // DIGIT: 1 if some q_I >= 4*q_J (else the lazy butterflies absorb the unreduced residue)
     u64 t;          // LIFT: plain modulus
     // STORE_MUL / STORE_MAC multiplier (NTT form): (mul_ptrs ? mul_ptrs[p / mul_item_polys] : mul)

@@ -138,12 +138,12 @@ static void fill_mod(ModDev &md, u64 q, int logn, u64 t, bool with_tables, u64 *
     const size_t n = (size_t)1 << logn;
     const u64 psi = nt_minimal_primitive_root(2 * n, q), ipsi = nt_invmod(psi, q);
     if (root_out) *root_out = psi;
-    u64 *w = host_tab, *ws = host_tab + n, *iw = host_tab + 2 * n, *iws = host_tab + 3 * n;
+    u64 *w = host_tab, *ws = host_tab + n, *iw = host_tab + 2 * n;
     u64 pw = 1, ipw = 1;
     for (size_t k = 0; k < n; ++k) {
         const size_t r = bit_reverse(k, logn);
         w[r] = pw; ws[r] = shoup_quot(pw, q);
-        iw[r] = ipw; iws[r] = shoup_quot(ipw, q);
+        iw[2 * r] = ipw; iw[2 * r + 1] = shoup_quot(ipw, q);
         pw = nt_mulmod(pw, psi, q);
         ipw = nt_mulmod(ipw, ipsi, q);
     }
@@ -151,7 +151,7 @@ static void fill_mod(ModDev &md, u64 q, int logn, u64 t, bool with_tables, u64 *
     md.ninv_s = shoup_quot(md.ninv, q);
     md.ninv_t = nt_mulmod(md.ninv, t % q, q);
     md.ninv_t_s = shoup_quot(md.ninv_t, q);
-    md.w = dev_tab; md.ws = dev_tab + n; md.iw = dev_tab + 2 * n; md.iws = dev_tab + 3 * n;
+    md.w = dev_tab; md.ws = dev_tab + n; md.iw = dev_tab + 2 * n;
 }
 
 // CoeffModulus::BFVDefault(N) (seal/coeffmodulus via util/globals.cpp, SEAL 4.0.0) as used by
@@ -312,6 +312,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
     if (const char *e = getenv("HHE_GRAPH")) c->use_graphs = atoi(e);
     if (const char *e = getenv("HHE_MACFUSE")) c->mac_fuse = atoi(e);
+    if (const char *e = getenv("HHE_LAZY8")) c->lazy8 = atoi(e);
     if (const char *e = getenv("HHE_SIDE")) c->side_stream = atoi(e);
     if (const char *e = getenv("HHE_PIPE_PROBE")) c->probe = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);

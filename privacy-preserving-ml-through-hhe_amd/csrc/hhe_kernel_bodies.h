@@ -150,15 +150,20 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
     }
 }
 
-// one register round: RHO stages starting at local stage S0 of a 2^LOGM transform
-template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE>
+// one register round: RHO stages starting at local stage S0 of a 2^LOGM transform.
+// Forward (CT) butterflies X' = X + wY, Y' = X - wY + 2q: wY comes out of the Shoup product in [0,2q) for ANY 64-bit Y, so
+// only the additive X chain grows, by 2q per stage.  Harvey's schedule folds X back below 2q at every stage ([0,4q)
+// invariant).  LAZY8 (all moduli of the launch < 2^60, i.e. 16q <= 2^64): fold once per round instead -- X >= 8q ? X - 8q
+// at the round's first stage, then up to four stages grow it to < 16q, which still fits 64 bits.  Saves RHO-1 of every RHO
+// conditional subtractions; the values stay congruent, so every fully reduced result is unchanged.
+template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false>
 HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
     const NttGeom g = ntt_geom(a, bx, by);
     const ModDev &m = a.mods[g.mod_index];
-    const u64 q = m.q, q2 = q << 1;
+    const u64 q = m.q, q2 = q << 1, q8 = q << 3;
     const u64 *W = INVERSE ? m.iw : m.w;
-    const u64 *WS = INVERSE ? m.iws : m.ws;
+    const u64 *WS = m.ws;
     constexpr int LO_BITS = LOGM - S0 - RHO;
     constexpr int RAD = 1 << RHO;
     const int groups = (g.M >> RHO) * g.C;
@@ -184,7 +189,8 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                     for (int j = 0; j < half; j++) {
                         const int k0 = b * 2 * half + j, k1 = k0 + half;
                         u64 x = v[k0];
-                        x -= (x >= q2) ? q2 : 0;
+                        if (LAZY8) { if (u == 0) x -= (x >= q8) ? q8 : 0; }
+                        else x -= (x >= q2) ? q2 : 0;
                         const u64 y = shoup_lazy(v[k1], w, ws, q);
                         v[k0] = x + y;
                         v[k1] = x + q2 - y;
@@ -197,7 +203,8 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                 const int half = 1 << (RHO - 1 - u);
 #pragma unroll
                 for (int b = 0; b < (1 << u); b++) {
-                    const u64 w = W[(tb << u) + b], ws = WS[(tb << u) + b];
+                    const U2 tw = ld2(W + 2 * (size_t)((tb << u) + b));
+                    const u64 w = tw.a, ws = tw.b;
 #pragma unroll
                     for (int j = 0; j < half; j++) {
                         const int k0 = b * 2 * half + j, k1 = k0 + half;
@@ -262,10 +269,16 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             return;
         }
     } else {
-        for (int k = 0; k < 2; k++) {
-            v[k] -= (v[k] >= q2) ? q2 : 0;
-            v[k] -= (v[k] >= q) ? q : 0;
-        }
+        // forward results arrive in [0,4q), or [0,16q) from LAZY8 rounds; a Barrett product takes them as they are
+        if (a.store_op != STORE_MUL && a.store_op != STORE_MAC)
+            for (int k = 0; k < 2; k++) {
+                if (a.lazy8) {
+                    v[k] -= (v[k] >= (q << 3)) ? (q << 3) : 0;
+                    v[k] -= (v[k] >= (q << 2)) ? (q << 2) : 0;
+                }
+                v[k] -= (v[k] >= q2) ? q2 : 0;
+                v[k] -= (v[k] >= q) ? q : 0;
+            }
         if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
             const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
             const U2 d = ld2(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);

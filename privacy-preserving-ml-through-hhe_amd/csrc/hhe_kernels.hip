@@ -78,14 +78,14 @@ template <int V, int LOGM, bool STRIDED, bool INVERSE>
 struct NttRounds {
     static constexpr int R = NttSchedV<V, LOGM>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
-    template <int I, int S0>
+    template <int I, int S0, bool LAZY8 = false>
     static __device__ __forceinline__ void fwd(const NttArgs &a, u64 *lds)
     {
         if constexpr (I < R) {
             constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
             __syncthreads();
-            fwd<I + 1, S0 + RHO>(a, lds);
+            fwd<I + 1, S0 + RHO, LAZY8>(a, lds);
         }
     }
     template <int I, int SEND>
@@ -109,8 +109,10 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
     ntt_body_load<STRIDED, INVERSE>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
     __syncthreads();
     if (!(a.probe & 4)) {  // probe bit 2: timing probe that skips the butterflies (memory pattern only)
-        if constexpr (!INVERSE) NttRounds<V, LOGM, STRIDED, INVERSE>::template fwd<0, 0>(a, lds);
-        else NttRounds<V, LOGM, STRIDED, INVERSE>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM>(a, lds);
+        if constexpr (!INVERSE) {
+            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE>::template fwd<0, 0, true>(a, lds);
+            else NttRounds<V, LOGM, STRIDED, INVERSE>::template fwd<0, 0, false>(a, lds);
+        } else NttRounds<V, LOGM, STRIDED, INVERSE>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM>(a, lds);
     }
     ntt_body_store<STRIDED, INVERSE>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
 }
@@ -194,9 +196,11 @@ void k_digit_mac(const NttArgs &a0, const KsMacArgs &mk, rt_stream s)
     default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", n2); break;
     }
 }
-void k_ntt_first_pass(const NttArgs &a, bool inverse, rt_stream s)
+void k_ntt_first_pass(const NttArgs &a0, bool inverse, rt_stream s)
 {
-    if (a.count <= 0) return;
+    if (a0.count <= 0) return;
+    NttArgs a = a0;
+    a.lazy8 = 0;  // the consumer (digit_mac_kernel) runs Harvey rounds on [0,4q) inputs
     int n1, n2;
     ntt_split(a.logn, n1, n2);
     if (!inverse) launch_pass<true, false>(a, n1, n2, (hipStream_t)s);

@@ -32,13 +32,13 @@ void *rt_capture_end(rt_stream) { return nullptr; }
 int rt_graph_launch(void *, rt_stream) { return -1; }
 void rt_graph_destroy(void *) {}
 
-template <int V, int LOGM, bool STRIDED, bool INVERSE, int I, int S0>
+template <int V, int LOGM, bool STRIDED, bool INVERSE, int I, int S0, bool LAZY8 = false>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (I < NttSchedV<V, LOGM>::R) {
         constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false>(a, bx, by, t, lds);
-        rounds_fwd<V, LOGM, STRIDED, INVERSE, I + 1, S0 + RHO>(a, bx, by, lds);
+        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8>(a, bx, by, t, lds);
+        rounds_fwd<V, LOGM, STRIDED, INVERSE, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
     }
 }
 template <int V, int LOGM, bool STRIDED, bool INVERSE, int I, int SEND>
@@ -60,7 +60,10 @@ static void pass_emu(const NttArgs &a, int gx, int gy)
         for (int by = 0; by < gy; by++)
             for (int bx = 0; bx < gx; bx++) {
                 for (int t = 0; t < NTT_THREADS; t++) ntt_body_load<STRIDED, INVERSE>(a, bx, by, t, lds.data());
-                if constexpr (!INVERSE) rounds_fwd<V, LOGM, STRIDED, INVERSE, 0, 0>(a, bx, by, lds.data());
+                if constexpr (!INVERSE) {
+                    if (a.lazy8) rounds_fwd<V, LOGM, STRIDED, INVERSE, 0, 0, true>(a, bx, by, lds.data());
+                    else rounds_fwd<V, LOGM, STRIDED, INVERSE, 0, 0, false>(a, bx, by, lds.data());
+                }
                 else rounds_inv<V, LOGM, STRIDED, INVERSE, NttSchedV<V, LOGM>::R - 1, LOGM>(a, bx, by, lds.data());
                 for (int t = 0; t < NTT_THREADS; t++) ntt_body_store<STRIDED, INVERSE>(a, bx, by, t, lds.data());
             }
@@ -146,9 +149,11 @@ void k_digit_mac(const NttArgs &a0, const KsMacArgs &mk, rt_stream)
     default: abort();
     }
 }
-void k_ntt_first_pass(const NttArgs &a, bool inverse, rt_stream)
+void k_ntt_first_pass(const NttArgs &a0, bool inverse, rt_stream)
 {
-    if (a.count <= 0) return;
+    if (a0.count <= 0) return;
+    NttArgs a = a0;
+    a.lazy8 = 0;
     int n1, n2;
     ntt_split(a.logn, n1, n2);
     if (!inverse) launch_pass<true, false>(a, n1, n2);
