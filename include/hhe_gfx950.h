@@ -55,7 +55,7 @@ int hhe_ctx_set_stream(hhe_ctx *c, void *hip_stream);
 int hhe_ctx_reserve(hhe_ctx *c, size_t max_batch);
 int hhe_ctx_sync(hhe_ctx *c);
 /* derived parameters, for cross-checking against SEAL's context: what in
- * {"root" i<K, "bsk" i<=L (B_0.., m_sk), "gamma", "galois_elt" i=step} */
+ * {"root" i<K, "bsk" i<=L (B_0.., m_sk), "gamma", "galois_elt" i=step, "fc_fallbacks"} */
 uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i);
 
 /* ---- keys: the by-value seal::RelinKeys / seal::GaloisKeys members of SEALZpCipher

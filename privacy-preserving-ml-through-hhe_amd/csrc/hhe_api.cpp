@@ -830,6 +830,111 @@ int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t
     k_ntt(r, true, c->w->stream);
     return HHE_OK;
 }
+// ---- shared digits (DESIGN.md "FC rotation trie", step 3) ----
+// All children of a trie node rotate the SAME ciphertext.  The digit transforms NTT_J(c1_I) are computed once per node;
+// for a child with Galois element g the transforms of the digits of galois_g(c1) are the NTT-domain index map of those
+// (read through the map inside ks_mac_kernel) plus q_I * NTT_J(s_g) for I != J, where s_g marks the coefficients whose
+// sign galois_g flips -- exact as long as no coefficient of c1 is 0 (a flipped 0 stays 0 instead of becoming q_I); the
+// digit loads raise zero_flag in that case and the caller recomputes with per-child transforms.  The key-dependent part
+// of the correction, NTT_J(s_g) * sum_{I != J} (q_I mod q_J) key_g[I][k][J], is tabulated once per Galois key.
+int fc_corr(hhe_ctx *c, u32 elt, const u64 *key, const u64 **out)
+{
+    auto it = c->d_gk_corr.find(elt);
+    if (it != c->d_gk_corr.end()) { *out = it->second; return HHE_OK; }
+    const int L = c->L, K = c->K;
+    const size_t n = c->n;
+    std::vector<u64> s((size_t)K * n, 0), qmod((size_t)L * K);
+    for (size_t i = 0; i < n; ++i) {  // GaloisTool::apply_galois (util/galois.h:32): i -> i*g mod 2N, negated when it wraps
+        const u64 raw = (u64)i * elt;
+        if ((raw >> c->logn) & 1) s[raw & (n - 1)] = 1;
+    }
+    for (int J = 1; J < K; ++J) memcpy(&s[(size_t)J * n], &s[0], n * 8);
+    for (int I = 0; I < L; ++I)
+        for (int J = 0; J < K; ++J) qmod[(size_t)I * K + J] = c->q[I] % c->q[J];
+    u64 *shat = (u64 *)rt_malloc((size_t)K * n * 8), *dq = (u64 *)rt_malloc(qmod.size() * 8), *corr = (u64 *)rt_malloc((size_t)2 * K * n * 8);
+    if (!shat || !dq || !corr) { rt_free(shat); rt_free(dq); rt_free(corr); return dev_fail("fc_corr"); }
+    rt_stream st = c->w->stream;
+    rt_h2d(shat, s.data(), s.size() * 8, st);
+    rt_h2d(dq, qmod.data(), qmod.size() * 8, st);
+    NttArgs a = ntt_args(c, shat, shat, K, 0, K);
+    k_ntt(a, false, st);
+    KsCorrArgs k;
+    k.key = key; k.shat = shat; k.qmod = dq; k.corr = corr; k.mods = c->d_mods; k.logn = c->logn; k.L = L; k.K = K;
+    k_ks_corr(k, st);
+    const int bad = rt_sync(st);  // host staging buffers and the temporaries go out of scope
+    rt_free(shat); rt_free(dq);
+    if (bad) { rt_free(corr); return dev_fail("fc_corr"); }
+    c->d_gk_corr[elt] = corr;
+    *out = corr;
+    return HHE_OK;
+}
+// digit transforms of the un-rotated c1 of `parent` into tp ([B][L][K][N], lazy range)
+void fc_parent_digits(hhe_ctx *c, const u64 *parent, u64 *tp, size_t B)
+{
+    const int L = c->L, K = c->K;
+    const size_t ln = (size_t)L * c->n;
+    NttArgs a = ntt_args(c, parent + ln, tp, B * L * K, 0, K);
+    a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = 2 * ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+    a.store_op = STORE_LAZY; a.zero_flag = c->w->zero_flag;
+    k_ntt(a, false, c->w->stream);
+}
+// one child of a node from the node's shared digit transforms: leaf (sums only) or full ciphertext into `cur`
+int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const FcLeafAcc *leaf, u64 *cur, size_t B)
+{
+    auto it = c->d_gk.find(elt);
+    if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    const u64 *corr = nullptr;
+    int rc = fc_corr(c, elt, it->second, &corr);
+    if (rc) return rc;
+    const int L = c->L, K = c->K;
+    const size_t n = c->n, ln = (size_t)L * n;
+    GaloisArgs g;
+    memset(&g, 0, sizeof(g));
+    g.mods = c->d_mods; g.logn = c->logn; g.count = (int)(B * L); g.L = L; g.einv = (u32)nt_invmod(elt, 2 * n);
+    g.in = parent; g.in_item_stride = 2 * ln;
+    if (leaf) { g.out = leaf->accG; g.out_item_stride = ln; g.accumulate = 1; }
+    else { g.out = cur; g.out_item_stride = 2 * ln; }   // c0' = galois(c0): base of the key switch
+    k_galois(g, c->w->stream);
+    KsMacArgs m;
+    memset(&m, 0, sizeof(m));
+    m.T = tp; m.key = it->second; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
+    m.perm_elt = elt; m.corr = corr;
+    if (leaf) m.s_acc = leaf->accS;
+    k_ks_mac(m, c->w->stream);
+    if (leaf) {
+        NttArgs r = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, leaf->rscr, B * 2, K - 1, 1);
+        r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RACC; r.acc = leaf->accH;
+        k_ntt(r, true, c->w->stream);
+        return HHE_OK;
+    }
+    op_ntt(c, c->w->ws_S, B * 2 * K, 0, K, true);
+    KsFinishArgs f = c->ksf;
+    f.S = c->w->ws_S; f.base = cur; f.base_item_stride = 2 * ln; f.base_mask = 1; f.out = cur; f.B = (int)B;
+    k_ks_finish(f, c->w->stream);
+    return HHE_OK;
+}
+int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out,
+                  const FcLeafAcc *acc, size_t B)
+{
+    if (trie[node].kids.empty()) return HHE_OK;
+    const size_t ctw = c->ct_words();
+    u64 *tp = c->w->ws_tp + (size_t)(depth - 1) * B * c->L * c->K * c->n;
+    fc_parent_digits(c, parent, tp, B);
+    for (int kid : trie[node].kids) {
+        const u32 elt = galois_elt_from_step(c, trie[kid].term);
+        if (acc && trie[kid].kids.empty() && trie[kid].mult == 1) {
+            int rc = fc_child_shared(c, parent, tp, elt, acc, nullptr, B);
+            if (rc) return rc;
+            continue;
+        }
+        u64 *cur = bufs + (size_t)depth * B * ctw;
+        int rc = fc_child_shared(c, parent, tp, elt, nullptr, cur, B);
+        if (rc) return rc;
+        for (int m = 0; m < trie[kid].mult; ++m) op_add(c, out, cur, out, B, 2);
+        if ((rc = fc_dfs_shared(c, trie, kid, depth + 1, cur, bufs, out, acc, B))) return rc;
+    }
+    return HHE_OK;
+}
 int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out,
            const FcLeafAcc *acc, size_t B)
 {
@@ -851,32 +956,69 @@ int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, co
 }
 }  // namespace
 
-static int fc_row_chunk(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
+// one chunk on lane `ln`, enqueued asynchronously; shared = the shared-digit evaluation (raises *ln.zero_flag when it is not exact)
+static int fc_row_chunk(hhe_ctx *c, Lane &ln, bool shared, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
                         int default_galois_only, uint64_t *out, size_t B);
 
 extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
                           int default_galois_only, uint64_t *out, size_t B)
 {
-    if (!c || W == 0) return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
-    // chunks keep the key-switch working set (digit transforms) inside the Infinity Cache; a chunk is a multiple of W
-    // so that item i of a chunk still uses weight row i % W
-    size_t per = c->fc_chunk ? c->fc_chunk : B;
-    if (per < B) per = std::max<size_t>(W, per / W * W);
-    for (size_t b0 = 0; b0 < B; b0 += per) {
-        const size_t bc = std::min(per, B - b0);
-        int rc = fc_row_chunk(c, vi + b0 * c->ct_words(), w, W, n_inputs, relin_slot, default_galois_only, out + b0 * c->ct_words(), bc);
-        if (rc) return rc;
-    }
-    return HHE_OK;
-}
-
-static int fc_row_chunk(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
-                        int default_galois_only, uint64_t *out, size_t B)
-{
-    if (!c || !vi || !w || !out || W == 0 || n_inputs == 0 || n_inputs > c->n / 2 || relin_slot < 0 || relin_slot >= HHE_RELIN_SLOTS)
+    if (!c || !vi || !w || !out || W == 0 || B == 0 || n_inputs == 0 || n_inputs > c->n / 2 || relin_slot < 0 || relin_slot >= HHE_RELIN_SLOTS)
         return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
     if (!c->d_rk_slot[relin_slot]) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
-    int rc = need(c, B);
+    // chunks keep the key-switch working set (digit transforms) inside the Infinity Cache; a chunk is a multiple of W
+    // so that item i of a chunk still uses weight row i % W.  Chunks are independent: they run round-robin on the
+    // internal streams (as in hhe_pasta3_transcipher), which fills the tails of each other's small launches.
+    size_t per = c->fc_chunk ? c->fc_chunk : B;
+    if (per < B) per = std::max<size_t>(W, per / W * W);
+    per = std::min(per, B);
+    const size_t nch = (B + per - 1) / per, ctw = c->ct_words();
+    const int ns = nch > 1 ? c->nstreams : 0;
+    Lane &main = c->lanes[0];
+    const bool shared = c->fc_shared != 0;
+    u32 *flags = nullptr;
+    if (shared) {
+        if (!(flags = (u32 *)rt_malloc(nch * 4))) return dev_fail("hhe_fc_row");
+        rt_memset(flags, 0, nch * 4, main.stream);
+    }
+    int rc = HHE_OK;
+    if (ns) {
+        rt_event_record(c->ev_fork, main.stream);
+        for (int s = 1; s <= ns; ++s) rt_stream_wait_event(c->lanes[s].stream, c->ev_fork);
+    }
+    size_t idx = 0;
+    for (size_t b0 = 0; b0 < B && !rc; b0 += per, ++idx) {
+        Lane &ln = ns ? c->lanes[1 + idx % ns] : main;
+        ln.zero_flag = shared ? flags + idx : nullptr;
+        rc = fc_row_chunk(c, ln, shared, vi + b0 * ctw, w, W, n_inputs, relin_slot, default_galois_only, out + b0 * ctw, std::min(per, B - b0));
+    }
+    for (int s = 1; s <= ns; ++s) {
+        rt_event_record(c->lanes[s].ev_done, c->lanes[s].stream);
+        rt_stream_wait_event(main.stream, c->lanes[s].ev_done);
+    }
+    c->w = &main;
+    if (shared && !rc) {
+        std::vector<u32> h(nch, 0);
+        if (rt_d2h(h.data(), flags, nch * 4, main.stream) || rt_sync(main.stream)) rc = dev_fail("hhe_fc_row");
+        // a zero coefficient in some c1 (probability ~ N/q per ciphertext): that chunk is recomputed with per-child transforms
+        idx = 0;
+        for (size_t b0 = 0; b0 < B && !rc; b0 += per, ++idx)
+            if (h[idx] || c->fc_shared == 2) {
+                c->fc_fallbacks++;
+                main.zero_flag = nullptr;
+                rc = fc_row_chunk(c, main, false, vi + b0 * ctw, w, W, n_inputs, relin_slot, default_galois_only, out + b0 * ctw, std::min(per, B - b0));
+            }
+    }
+    if (rt_sync(main.stream) && !rc) rc = dev_fail("hhe_fc_row");
+    rt_free(flags);
+    return rc;
+}
+
+static int fc_row_chunk(hhe_ctx *c, Lane &lane, bool shared, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
+                        int default_galois_only, uint64_t *out, size_t B)
+{
+    c->w = &lane;
+    int rc = lane_reserve(c, lane, B);
     if (rc) return rc;
     const int L = c->L;
     const size_t ctw = c->ct_words();
@@ -927,20 +1069,37 @@ static int fc_row_chunk(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_
     rc = op_relinearize(c, ln.ws_ct3, prod, B);                            // CSP.cpp:306
     c->d_rk = saved;
     if (rc) return rc;
-    rt_d2d(out, prod, B * ctw * 8, ln.stream);
-    if (!c->fc_leaf_sums) return fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, nullptr, B);
     const size_t bln = B * (size_t)L * c->n;
-    FcLeafAcc acc;
-    acc.accS = ln.ws_ct[0]; acc.accH = ln.ws_ct[1]; acc.accG = ln.ws_ct[2]; acc.rscr = ln.ws_ct[2] + bln;
-    rt_memset(acc.accS, 0, 2 * bln * 8, ln.stream);
-    rt_memset(acc.accH, 0, 2 * bln * 8, ln.stream);
-    rt_memset(acc.accG, 0, bln * 8, ln.stream);
-    if ((rc = fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, &acc, B))) return rc;
-    op_ntt(c, acc.accS, B * 2 * L, 0, L, true);
-    LeafSumArgs ls;
-    memset(&ls, 0, sizeof(ls));
-    ls.accG = acc.accG; ls.accS = acc.accS; ls.accH = acc.accH; ls.out = out; ls.mods = c->d_mods; ls.logn = c->logn;
-    ls.B = (int)B; ls.L = L; ls.ks = c->ksc;
-    k_leaf_sum(ls, ln.stream);
-    return HHE_OK;
+    // one evaluation of the rotation trie; shared = children of a node reuse the digit transforms of its c1
+    auto run = [&](bool shared) -> int {
+        rt_d2d(out, prod, B * ctw * 8, ln.stream);
+        auto dfs = [&](const FcLeafAcc *acc) {
+            return shared ? fc_dfs_shared(c, trie, 0, 1, prod, ln.ws_rot, out, acc, B) : fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, acc, B);
+        };
+        if (!c->fc_leaf_sums) return dfs(nullptr);
+        FcLeafAcc acc;
+        acc.accS = ln.ws_ct[0]; acc.accH = ln.ws_ct[1]; acc.accG = ln.ws_ct[2]; acc.rscr = ln.ws_ct[2] + bln;
+        rt_memset(acc.accS, 0, 2 * bln * 8, ln.stream);
+        rt_memset(acc.accH, 0, 2 * bln * 8, ln.stream);
+        rt_memset(acc.accG, 0, bln * 8, ln.stream);
+        int r = dfs(&acc);
+        if (r) return r;
+        op_ntt(c, acc.accS, B * 2 * L, 0, L, true);
+        LeafSumArgs ls;
+        memset(&ls, 0, sizeof(ls));
+        ls.accG = acc.accG; ls.accS = acc.accS; ls.accH = acc.accH; ls.out = out; ls.mods = c->d_mods; ls.logn = c->logn;
+        ls.B = (int)B; ls.L = L; ls.ks = c->ksc;
+        k_leaf_sum(ls, ln.stream);
+        return HHE_OK;
+    };
+    if (!shared || max_depth == 0) return run(false);
+    const size_t tp_words = B * (size_t)L * c->K * c->n;
+    if (ln.tp_cap < B || ln.tp_depth < (size_t)max_depth) {
+        rt_sync(ln.stream);
+        rt_free(ln.ws_tp);
+        ln.ws_tp = (u64 *)rt_malloc((size_t)max_depth * tp_words * 8);
+        if (!ln.ws_tp) { ln.tp_cap = ln.tp_depth = 0; return dev_fail("hhe_fc_row workspace"); }
+        ln.tp_cap = B; ln.tp_depth = (size_t)max_depth;
+    }
+    return run(true);
 }

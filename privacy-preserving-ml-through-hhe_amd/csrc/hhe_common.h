@@ -66,6 +66,7 @@ struct NttArgs {
     size_t src_item_stride;  // words between items in src
     int load_op, store_op;
     int probe;         // timing probes (tools/ntt_micro.py): bit 2 = skip the butterflies
+    u32 *zero_flag;    // LOAD_DIGIT: set to 1 when a coefficient equals 0 (the shared-digit FC path then falls back)
     int lazy8;         // every modulus of the launch is below 2^60: forward butterflies correct X once per register round ([0,16q) range)
     int digit_reduce;  // DIGIT: 1 if some q_I >= 4*q_J (else the lazy butterflies absorb the unreduced residue)
     u64 t;          // LIFT: plain modulus
@@ -117,6 +118,21 @@ struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
     u64 *acc;
     const u64 *const *mul_ptrs;
     size_t mul_shift;
+    // optional (FC shared digits): T holds the digit transforms of the UN-rotated c1; the rotation by perm_elt is applied
+    // as the NTT-domain index map while reading T, and corr[k][J][n] (KsCorrArgs) is added to the sums
+    u32 perm_elt;
+    const u64 *corr;  // [2][K][N]
+};
+// Correction of the shared-digit key switch (DESIGN.md "FC rotation trie"): the digit d_I of galois_g(c1) differs from
+// galois_g applied mod q_J to the digit of c1 by q_I at every sign-flipped, non-zero coefficient, so
+//   corr[k][J] = NTT_J(s_g) * sum_{I != J} (q_I mod q_J) * key_g[I][k][J]     (s_g = 0/1 polynomial of the flipped positions)
+struct KsCorrArgs {
+    const u64 *key;    // [L][2][K][N]
+    const u64 *shat;   // [K][N] NTT_J(s_g)
+    const u64 *qmod;   // [L][K]  q_I mod q_J
+    u64 *corr;         // [2][K][N]
+    const ModDev *mods;
+    int logn, L, K;
 };
 
 struct PermArgs {  // NTT-domain Galois permutation: out[p][x] (op)= in[p][pi_elt(x)] (* mul)

@@ -316,6 +316,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     if (const char *e = getenv("HHE_SIDE")) c->side_stream = atoi(e);
     if (const char *e = getenv("HHE_PIPE_PROBE")) c->probe = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
+    if (const char *e = getenv("HHE_FC_SHARED")) c->fc_shared = atoi(e);
     if (const char *e = getenv("HHE_FC_CHUNK")) c->fc_chunk = (size_t)std::max(0, atoi(e));
     if (const char *e = getenv("HHE_DIGIT_SUB")) c->digit_sub = (size_t)std::max(0, atoi(e));
     if (const char *e = getenv("HHE_STREAMS")) c->nstreams = std::max(0, std::min(HHE_MAX_STREAMS, atoi(e)));
@@ -345,6 +346,7 @@ static void free_lane(Lane &ln)
     rt_free(ln.ws_T); rt_free(ln.ws_S); rt_free(ln.ws_d); rt_free(ln.ws_ct3); rt_free(ln.ws_plain); rt_free(ln.ws_vals);
     for (auto &p : ln.ws_ct) { rt_free(p); p = nullptr; }
     rt_free(ln.ws_rot); ln.ws_rot = nullptr; ln.rot_cap = 0;
+    rt_free(ln.ws_tp); ln.ws_tp = nullptr; ln.tp_cap = ln.tp_depth = 0;
     for (auto &kv : ln.graphs) rt_graph_destroy(kv.second);
     ln.graphs.clear();
     rt_free((void *)ln.d_ptrs); ln.d_ptrs = nullptr; ln.ptr_cap = 0;
@@ -412,6 +414,7 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
     rt_event_destroy(c->ev_fork);
     for (auto &p : c->d_rk_slot) rt_free(p);
     for (auto &kv : c->d_gk) rt_free(kv.second);
+    for (auto &kv : c->d_gk_corr) rt_free(kv.second);
     rt_free(c->d_feistel_mask);
     rt_free(c->d_tables); rt_free(c->d_mods); rt_free(c->d_behz); rt_free(c->d_slot_map);
     delete c;
@@ -455,6 +458,7 @@ extern "C" uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i)
     if (w == "galois_elt") return galois_elt_from_step(c, i);
     if (w == "delta" && i >= 0 && i < c->L) return c->apl.delta[i];
     if (w == "slot_map" && i >= 0 && (size_t)i < c->n) return c->slot_map[i];
+    if (w == "fc_fallbacks") return c->fc_fallbacks;
     return 0;
 }
 
@@ -478,6 +482,8 @@ extern "C" int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk) { return hhe_s
 extern "C" int hhe_set_galois_key(hhe_ctx *c, uint32_t elt, const uint64_t *ksk)
 {
     if (!c || !ksk || !(elt & 1) || elt >= 2 * c->n) { hhe_set_error("hhe_set_galois_key: invalid Galois element"); return HHE_ERR_INVALID; }
+    auto corr = c->d_gk_corr.find(elt);  // derived from the key being replaced
+    if (corr != c->d_gk_corr.end()) { rt_sync(c->lanes[0].stream); rt_free(corr->second); c->d_gk_corr.erase(corr); }
     u64 *&slot = c->d_gk[elt];
     return upload_key(c, slot, ksk);
 }

@@ -38,6 +38,9 @@ struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `c
     std::map<std::pair<int, size_t>, void *> graphs;  // (affine layer, batch) -> captured fused-matmul graph
     u64 *ws_rot = nullptr;   // [B][16][2][L][N] babystep rotations (allocated on first BSGS use)
     size_t rot_cap = 0;
+    u64 *ws_tp = nullptr;    // FC shared digits: [depth][B][L][K][N] digit transforms of the un-rotated c1 of each trie level
+    size_t tp_cap = 0, tp_depth = 0;
+    u32 *zero_flag = nullptr; // device flag of the chunk this lane is evaluating (shared-digit FC)
 };
 
 struct hhe_ctx {
@@ -54,6 +57,8 @@ struct hhe_ctx {
     int use_graphs = 1;            // replay the fused matmul loop (1143 launches per layer) as a hipGraph on internal streams
     int side_stream = 0;           // overlap the off-critical-path c0 update (K5) with the next digit transforms
     int probe = 0;                 // HHE_PIPE_PROBE timing probes (bench only; results invalid when set)
+    u64 fc_fallbacks = 0;          // how often the shared-digit path had to be recomputed exactly
+    int fc_shared = 1;             // FC rotation trie: children of a node share the digit transforms of its c1 (HHE_FC_SHARED; 2 = force the fallback, tests)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
     size_t fc_chunk = 40;          // items per internal chunk of hhe_fc_row (0 = whole batch)
     size_t digit_sub = 0;          // >0: run the digit transforms + inner product in sub-batches of this many items (T stays cache resident)
@@ -77,6 +82,7 @@ struct hhe_ctx {
     u64 *d_rk = nullptr;                       // slot 0 (transciphering)
     u64 *d_rk_slot[HHE_RELIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     std::map<u32, u64 *> d_gk;
+    std::map<u32, u64 *> d_gk_corr;            // per Galois key: shared-digit correction [2][K][N] (KsCorrArgs), built on first FC use
 
     // PASTA public tables
     std::map<u64, BlockTables> blocks;

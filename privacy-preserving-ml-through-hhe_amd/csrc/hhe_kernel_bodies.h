@@ -75,6 +75,14 @@ template <bool STRIDED> HD int ntt_gidx(const NttGeom &g, int x, int lane)
 struct alignas(16) U2 { u64 a, b; };
 HD U2 ld2(const u64 *p) { return *reinterpret_cast<const U2 *>(p); }   // 16 B per lane: the coalescing sweet spot
 HD void st2(u64 *p, U2 v) { *reinterpret_cast<U2 *>(p) = v; }
+// (in[pi(x)], in[pi(x+1)]) for even x with one 16-byte load: x and x+1 differ in the top bit of their bit reversal, the
+// odd exponents 2*bitrev+1 then differ by N, so do their products with the (odd) Galois element, hence pi(x+1) = pi(x) ^ 1
+HD U2 ld2_perm(const u64 *base, u32 x_even, int logn, u32 elt)
+{
+    const u32 p0 = ntt_perm_index(x_even, logn, elt);
+    const U2 v = ld2(base + (p0 & ~1u));
+    return (p0 & 1) ? U2{v.b, v.a} : v;
+}
 
 // element pair handled by one lane in the load/store phases: (x, lane) and its neighbour in global memory
 template <bool STRIDED> HD void ntt_pair(const NttArgs &a, const NttGeom &g, int e2, int &x, int &lane, int &gi, int &lds0, int &lds1)
@@ -88,7 +96,10 @@ template <bool STRIDED> HD void ntt_pair(const NttArgs &a, const NttGeom &g, int
 template <bool FIRST> HD U2 ntt_load_op(const NttArgs &a, const ModDev &m, int poly, U2 v)
 {
     if (FIRST) {
-        if (a.load_op == LOAD_DIGIT) { if (a.digit_reduce) { v.a = reduce64(v.a, m); v.b = reduce64(v.b, m); } }
+        if (a.load_op == LOAD_DIGIT) {
+            if (a.zero_flag && (v.a == 0 || v.b == 0)) *a.zero_flag = 1;
+            if (a.digit_reduce) { v.a = reduce64(v.a, m); v.b = reduce64(v.b, m); }
+        }
         else if (a.load_op == LOAD_LIFT) {
             const u64 thr = (a.t + 1) >> 1, inc = m.q - a.t;
             v.a = (v.a >= thr) ? v.a + inc : v.a;
@@ -297,8 +308,8 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             const U2 d = ld2(a.mul_ptrs[item] + a.mul_shift + (size_t)j * g.n + gi);
             const U2 s0 = ld2(a.aux_r + ((item * 2 + 0) * a.K + j) * g.n + gi);
             U2 acc = ld2(a.acc + pbase + gi);
-            const u64 g0 = a.aux_in[pbase + ntt_perm_index((u32)gi, a.logn, a.gal_elt)];
-            const u64 g1 = a.aux_in[pbase + ntt_perm_index((u32)gi + 1, a.logn, a.gal_elt)];
+            const U2 gp = ld2_perm(a.aux_in + pbase, (u32)gi, a.logn, a.gal_elt);
+            const u64 g0 = gp.a, g1 = gp.b;
             acc.a = addmod(acc.a, mulmod(g0, d.a, m), q);
             acc.b = addmod(acc.b, mulmod(g1, d.b, m), q);
             st2(a.acc + pbase + gi, acc);
@@ -399,8 +410,12 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
     if (b >= (size_t)a.B) return;
     const ModDev &m = a.mods[J];
     Acc128 s0[2] = {{0, 0}, {0, 0}}, s1[2] = {{0, 0}, {0, 0}};
+    u32 p0 = (u32)i;
+    if (a.perm_elt) p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt);
     for (int I = 0; I < a.L; I++) {
-        const U2 t = ld2(a.T + ((b * a.L + I) * a.K + J) * n + i);
+        const u64 *tp = a.T + ((b * a.L + I) * a.K + J) * n;
+        U2 t = ld2(tp + (p0 & ~1u));  // shared digits: pair (pi(i), pi(i+1)) = aligned pair, possibly swapped (ld2_perm)
+        if (p0 & 1) t = U2{t.b, t.a};
         const U2 k0 = ld2(a.key + (((size_t)I * 2 + 0) * a.K + J) * n + i);
         const U2 k1 = ld2(a.key + (((size_t)I * 2 + 1) * a.K + J) * n + i);
         if (a.acc && I == J) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product
@@ -420,6 +435,11 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
             }
         }
     }
+    if (a.corr) {
+        const U2 e0 = ld2(a.corr + ((size_t)0 * a.K + J) * n + i), e1 = ld2(a.corr + ((size_t)1 * a.K + J) * n + i);
+        acc_add(s0[0], e0.a); acc_add(s0[1], e0.b);
+        acc_add(s1[0], e1.a); acc_add(s1[1], e1.b);
+    }
     const U2 r0 = {barrett128(s0[0].lo, s0[0].hi, m), barrett128(s0[1].lo, s0[1].hi, m)};
     const U2 r1 = {barrett128(s1[0].lo, s1[0].hi, m), barrett128(s1[1].lo, s1[1].hi, m)};
     if (a.s_acc && J < a.L) {  // leaf of the FC rotation trie: only the sum over leaves is ever inverse-transformed
@@ -432,6 +452,20 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
     }
     st2(a.S + ((b * 2 + 0) * a.K + J) * n + i, r0);
     st2(a.S + ((b * 2 + 1) * a.K + J) * n + i, r1);
+}
+
+// gid over [2][K][N]
+HD void ks_corr_body(const KsCorrArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    if (gid >= (size_t)2 * a.K * n) return;
+    const size_t x = gid & (n - 1);
+    const int J = (int)((gid >> a.logn) % a.K), k = (int)(gid >> a.logn) / a.K;
+    const ModDev &m = a.mods[J];
+    u64 sum = 0;
+    for (int I = 0; I < a.L; I++)
+        if (I != J) sum = addmod(sum, mulmod(a.key[(((size_t)I * 2 + k) * a.K + J) * n + x], a.qmod[I * a.K + J], m), m.q);
+    a.corr[gid] = mulmod(sum, a.shat[(size_t)J * n + x], m);
 }
 
 // Fused digit NTT + key-switch inner product (row pass of NTT_J(d_I mod q_J), V = 1 tiles): after the last

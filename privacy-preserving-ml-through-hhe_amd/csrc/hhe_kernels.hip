@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(ELT_THREADS) elt_kernel(EltArgs a, int op) { e
 __global__ void __launch_bounds__(ELT_THREADS) galois_kernel(GaloisArgs a) { galois_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) perm_kernel(PermArgs a) { perm_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_mac_kernel(KsMacArgs a) { ks_mac_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) ks_corr_kernel(KsCorrArgs a) { ks_corr_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_finish_kernel(KsFinishArgs a) { ks_finish_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) leaf_sum_kernel(LeafSumArgs a) { leaf_sum_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) add_plain_kernel(AddPlainArgs a) { add_plain_body(a, GID); }
@@ -250,6 +251,7 @@ void k_elt(const EltArgs &a, int op, rt_stream s) { LAUNCH1D(elt_kernel, (size_t
 void k_galois(const GaloisArgs &a, rt_stream s) { LAUNCH1D(galois_kernel, (size_t)a.count << a.logn, s, a); }
 void k_perm(const PermArgs &a, rt_stream s) { LAUNCH1D(perm_kernel, (size_t)a.count << a.logn, s, a); }
 void k_ks_mac(const KsMacArgs &a, rt_stream s) { LAUNCH1D(ks_mac_kernel, ((size_t)a.B * a.K) << (a.logn - 1), s, a); }
+void k_ks_corr(const KsCorrArgs &a, rt_stream s) { LAUNCH1D(ks_corr_kernel, ((size_t)2 * a.K) << a.logn, s, a); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream s) { LAUNCH1D(ks_finish_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s) { LAUNCH1D(leaf_sum_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
 void k_add_plain(const AddPlainArgs &a, rt_stream s) { LAUNCH1D(add_plain_kernel, (size_t)a.B << a.logn, s, a); }

@@ -40,6 +40,7 @@ void k_elt(const EltArgs &a, int op, rt_stream s);
 void k_galois(const GaloisArgs &a, rt_stream s);
 void k_perm(const PermArgs &a, rt_stream s);
 void k_ks_mac(const KsMacArgs &a, rt_stream s);
+void k_ks_corr(const KsCorrArgs &a, rt_stream s);
 void k_ks_finish(const KsFinishArgs &a, rt_stream s);
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s);
 void k_add_plain(const AddPlainArgs &a, rt_stream s);

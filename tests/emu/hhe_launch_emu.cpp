@@ -176,6 +176,7 @@ void k_elt(const EltArgs &a, int op, rt_stream) { LOOP((size_t)a.count << a.logn
 void k_galois(const GaloisArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, galois_body(a, (size_t)g)); }
 void k_perm(const PermArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, perm_body(a, (size_t)g)); }
 void k_ks_mac(const KsMacArgs &a, rt_stream) { LOOP(((size_t)a.B * a.K) << (a.logn - 1), ks_mac_body(a, (size_t)g)); }
+void k_ks_corr(const KsCorrArgs &a, rt_stream) { LOOP(((size_t)2 * a.K) << a.logn, ks_corr_body(a, (size_t)g)); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, ks_finish_body(a, (size_t)g)); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, leaf_sum_body(a, (size_t)g)); }
 void k_add_plain(const AddPlainArgs &a, rt_stream) { LOOP((size_t)a.B << a.logn, add_plain_body(a, (size_t)g)); }

@@ -195,3 +195,30 @@ def check_decrypt(X, S, mem, B=3, seed=0):
     for b in range(B):
         assert (got[b] == O.decode(O.decrypt(S.sk, cts[b]))).all()
     assert (got[0] == vals[0]).all()
+
+
+def check_fc_variants(make_ctx, S, orc, mem, monkeypatch, n_in=37):
+    """hhe_fc_row execution variants (per-child digit transforms, shared digits, forced exact fallback, with and without
+    leaf sums) all return the oracle's words."""
+    O = S.O
+    rng = np.random.default_rng(8)
+    v, w = rng.integers(0, 4, n_in), rng.integers(-8, 9, n_in)
+    wc = O.encrypt(S.pk, O.encode(w), 43)
+    B = 3
+    vi = np.stack([O.encrypt(S.pk, O.encode(v), 41 + b) for b in range(B)])
+    refs = [O.fc_row(vi[b], wc, S.rk, S.gk, n_in)[0] for b in range(B)]
+    # (shared digits, leaf sums, items per chunk): chunk 1 -> three chunks round-robin over the internal streams
+    for shared, leafsum, chunk in (("1", "1", "40"), ("0", "1", "40"), ("2", "1", "40"), ("1", "0", "40"), ("0", "0", "40"),
+                                   ("1", "1", "1"), ("2", "1", "1"), ("0", "1", "2")):
+        monkeypatch.setenv("HHE_FC_SHARED", shared)
+        monkeypatch.setenv("HHE_FC_LEAFSUM", leafsum)
+        monkeypatch.setenv("HHE_FC_CHUNK", chunk)
+        X = make_ctx()
+        S.load_keys(X)
+        out = mem.empty((B,) + O.ct_shape)
+        X.fc_row(mem.to_dev(vi), mem.to_dev(wc[None]), 1, n_in, out, B, relin_slot=0, default_galois_only=False)
+        got = mem.to_host(out)
+        for b in range(B):
+            assert (got[b] == refs[b]).all(), (shared, leafsum, b)
+        assert X.query("fc_fallbacks") == ((B + int(chunk) - 1) // int(chunk) if shared == "2" else 0)
+        X.close()

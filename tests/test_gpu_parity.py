@@ -321,3 +321,8 @@ def test_end_to_end_client_encrypt_csp_transcipher_analyst_decrypt(orc, api, lib
     X.decrypt(S.sk, out, 2, vals)
     got = mem.to_host(vals)
     assert (got[:, :300] == pts).all() and not got[:, 300:S.O.n // 2].any()
+
+
+def test_fc_row_shared_digit_variants(orc, api, lib, mem, monkeypatch):
+    S = Setup(orc, 11, [60] * 4, all_galois=True)
+    pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=lib), S, orc, mem, monkeypatch, n_in=100)

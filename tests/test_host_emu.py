@@ -298,3 +298,8 @@ def test_analyst_batched_decrypt_matches_oracle(orc, api, emu_lib, mem, small):
     X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
     small.load_keys(X)
     pc.check_decrypt(X, small, mem)
+
+
+def test_fc_row_shared_digit_variants(orc, api, emu_lib, mem, monkeypatch):
+    S = Setup(orc, 10, [50] * 4, all_galois=True)
+    pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=emu_lib), S, orc, mem, monkeypatch)
