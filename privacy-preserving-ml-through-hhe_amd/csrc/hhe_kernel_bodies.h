@@ -49,17 +49,21 @@ HD u32 ntt_perm_index(u32 x, int logn, u32 elt)
 }
 
 struct NttGeom {
-    int n, M, C, pitch, N_over_M;
+    int n, M, C, pitch, N_over_M, logm, logc;
     int poly, mod_index, tile;
 };
-HD NttGeom ntt_geom(const NttArgs &a, int bx, int by)
+// CM / CC >= 0: pass size and tile columns known at compile time (full tiles: every launch with N >= 4096), so the LDS
+// pitch, masks and per-pair strides fold into immediates; -1: taken from the launch arguments (ragged small-N tiles)
+template <int CM = -1, int CC = -1> HD NttGeom ntt_geom(const NttArgs &a, int bx, int by)
 {
     NttGeom g;
+    g.logm = CM >= 0 ? CM : a.logm;
+    g.logc = CC >= 0 ? CC : a.logc;
     g.n = 1 << a.logn;
-    g.M = 1 << a.logm;
-    g.C = 1 << a.logc;
+    g.M = 1 << g.logm;
+    g.C = 1 << g.logc;
     g.pitch = g.C + 1;
-    g.N_over_M = g.n >> a.logm;
+    g.N_over_M = g.n >> g.logm;
     g.poly = by;
     g.mod_index = a.mod_base + by % a.mod_cycle;
     g.tile = bx;
@@ -87,8 +91,8 @@ HD U2 ld2_perm(const u64 *base, u32 x_even, int logn, u32 elt)
 // element pair handled by one lane in the load/store phases: (x, lane) and its neighbour in global memory
 template <bool STRIDED> HD void ntt_pair(const NttArgs &a, const NttGeom &g, int e2, int &x, int &lane, int &gi, int &lds0, int &lds1)
 {
-    if (STRIDED) { lane = (e2 & ((g.C >> 1) - 1)) << 1; x = e2 >> (a.logc - 1); lds0 = x * g.pitch + lane; lds1 = lds0 + 1; }
-    else { x = (e2 & ((g.M >> 1) - 1)) << 1; lane = e2 >> (a.logm - 1); lds0 = x * g.pitch + lane; lds1 = lds0 + g.pitch; }
+    if (STRIDED) { lane = (e2 & ((g.C >> 1) - 1)) << 1; x = e2 >> (g.logc - 1); lds0 = x * g.pitch + lane; lds1 = lds0 + 1; }
+    else { x = (e2 & ((g.M >> 1) - 1)) << 1; lane = e2 >> (g.logm - 1); lds0 = x * g.pitch + lane; lds1 = lds0 + g.pitch; }
     gi = ntt_gidx<STRIDED>(g, x, lane);
 }
 
@@ -135,11 +139,11 @@ HD void ntt_load_full(const NttArgs &a, const NttGeom &g, const ModDev &m, const
     }
 }
 
-template <bool STRIDED, bool INVERSE>
+template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1>
 HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
     constexpr bool FIRST = (STRIDED != INVERSE);
-    const NttGeom g = ntt_geom(a, bx, by);
+    const NttGeom g = ntt_geom<CM, CC>(a, bx, by);
     const ModDev &m = a.mods[g.mod_index];
     const u64 *src;
     if (FIRST) {
@@ -167,10 +171,10 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 // invariant).  LAZY8 (all moduli of the launch < 2^60, i.e. 16q <= 2^64): fold once per round instead -- X >= 8q ? X - 8q
 // at the round's first stage, then up to four stages grow it to < 16q, which still fits 64 bits.  Saves RHO-1 of every RHO
 // conditional subtractions; the values stay congruent, so every fully reduced result is unchanged.
-template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false>
+template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1>
 HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
-    const NttGeom g = ntt_geom(a, bx, by);
+    const NttGeom g = ntt_geom<(CC >= 0 ? LOGM : -1), CC>(a, bx, by);
     const ModDev &m = a.mods[g.mod_index];
     const u64 q = m.q, q2 = q << 1, q8 = q << 3;
     const u64 *W = INVERSE ? m.iw : m.w;
@@ -180,7 +184,7 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
     const int groups = (g.M >> RHO) * g.C;
     for (int grp = tid; grp < groups; grp += NTT_THREADS) {
         const int lane = grp & (g.C - 1);
-        const int sub = grp >> a.logc;
+        const int sub = grp >> g.logc;
         const int hi = sub >> LO_BITS;
         const int lo = sub & ((1 << LO_BITS) - 1);
         const int x0 = (hi << (LOGM - S0)) + lo;
@@ -323,10 +327,10 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
     st2(dst + gi, U2{v[0], v[1]});
 }
 
-template <bool STRIDED, bool INVERSE>
+template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1>
 HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds)
 {
-    const NttGeom g = ntt_geom(a, bx, by);
+    const NttGeom g = ntt_geom<CM, CC>(a, bx, by);
     const ModDev &m = a.mods[g.mod_index];
     u64 *dst = a.dst + (size_t)g.poly * g.n;
     const size_t pbase = (size_t)g.poly * g.n;

@@ -74,7 +74,8 @@ void rt_graph_destroy(void *exec) { if (exec) (void)hipGraphExecDestroy((hipGrap
 #define NTT_BX(a) ((int)(blockIdx.x & ((1u << (a).tiles_log) - 1)))
 #define NTT_BY(a) ((int)(blockIdx.x >> (a).tiles_log))
 
-template <int V, int LOGM, bool STRIDED, bool INVERSE>
+// CC = tile columns as a compile-time constant (full tiles) or -1 (ragged tiles of small N: taken from the arguments)
+template <int V, int LOGM, bool STRIDED, bool INVERSE, int CC>
 struct NttRounds {
     static constexpr int R = NttSchedV<V, LOGM>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
@@ -83,7 +84,7 @@ struct NttRounds {
     {
         if constexpr (I < R) {
             constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
             __syncthreads();
             fwd<I + 1, S0 + RHO, LAZY8>(a, lds);
         }
@@ -93,7 +94,7 @@ struct NttRounds {
     {
         if constexpr (I >= 0) {
             constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, false, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
             __syncthreads();
             inv<I - 1, SEND - RHO>(a, lds);
         }
@@ -101,20 +102,22 @@ struct NttRounds {
 };
 
 // V = 0: 4096-point tiles (bulk launches); V = 1: 2048-point tiles -- twice the workgroups, half the lifetime each,
-// used when a launch would not even fill the 1024 resident workgroup slots once (latency-bound small batches)
-template <int V, int LOGM, bool STRIDED, bool INVERSE>
+// used when a launch would not even fill the 1024 resident workgroup slots once (latency-bound small batches).
+// FULL: the tile is 2^LOGM points x 2^(tile log - LOGM) columns (every launch with N >= 4096) -> geometry folds into constants
+template <int V, int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
 {
+    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile<V>::LOG - LOGM : -1;
     __shared__ u64 lds[NttLds<V>::ELEMS];
-    ntt_body_load<STRIDED, INVERSE>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+    ntt_body_load<STRIDED, INVERSE, CM, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
     __syncthreads();
     if (!(a.probe & 4)) {  // probe bit 2: timing probe that skips the butterflies (memory pattern only)
         if constexpr (!INVERSE) {
-            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE>::template fwd<0, 0, true>(a, lds);
-            else NttRounds<V, LOGM, STRIDED, INVERSE>::template fwd<0, 0, false>(a, lds);
-        } else NttRounds<V, LOGM, STRIDED, INVERSE>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM>(a, lds);
+            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, true>(a, lds);
+            else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, false>(a, lds);
+        } else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM>(a, lds);
     }
-    ntt_body_store<STRIDED, INVERSE>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+    ntt_body_store<STRIDED, INVERSE, CM, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
 }
 
 static int g_small_wgs = -1;
@@ -129,13 +132,17 @@ static void launch_pass_v(NttArgs a, int logm, int other, hipStream_t st)
     dim3 grid((unsigned)(((size_t)a.count) << a.tiles_log));
     static int dyn_lds = -1;  // occupancy probe: extra dynamic LDS per workgroup (HHE_NTT_DYNLDS bytes)
     if (dyn_lds < 0) { const char *e = getenv("HHE_NTT_DYNLDS"); dyn_lds = e ? atoi(e) : 0; }
+    const bool full = logc == NttTile<V>::LOG - logm;
+#define NTT_LAUNCH(M_)                                                                                                           \
+    case M_:                                                                                                                     \
+        if (full) hipLaunchKernelGGL((ntt_pass_kernel<V, M_, STRIDED, INVERSE, true>), grid, dim3(NTT_THREADS), dyn_lds, st, a); \
+        else hipLaunchKernelGGL((ntt_pass_kernel<V, M_, STRIDED, INVERSE, false>), grid, dim3(NTT_THREADS), dyn_lds, st, a);     \
+        break;
     switch (logm) {
-    case 5: hipLaunchKernelGGL((ntt_pass_kernel<V, 5, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
-    case 6: hipLaunchKernelGGL((ntt_pass_kernel<V, 6, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
-    case 7: hipLaunchKernelGGL((ntt_pass_kernel<V, 7, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
-    case 8: hipLaunchKernelGGL((ntt_pass_kernel<V, 8, STRIDED, INVERSE>), grid, dim3(NTT_THREADS), dyn_lds, st, a); break;
+        NTT_LAUNCH(5) NTT_LAUNCH(6) NTT_LAUNCH(7) NTT_LAUNCH(8)
     default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", logm); break;
     }
+#undef NTT_LAUNCH
 }
 template <bool STRIDED, bool INVERSE>
 static void launch_pass(const NttArgs &a, int logm, int other, hipStream_t st)

@@ -32,40 +32,41 @@ void *rt_capture_end(rt_stream) { return nullptr; }
 int rt_graph_launch(void *, rt_stream) { return -1; }
 void rt_graph_destroy(void *) {}
 
-template <int V, int LOGM, bool STRIDED, bool INVERSE, int I, int S0, bool LAZY8 = false>
+template <int V, int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int S0, bool LAZY8 = false>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (I < NttSchedV<V, LOGM>::R) {
         constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8>(a, bx, by, t, lds);
-        rounds_fwd<V, LOGM, STRIDED, INVERSE, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
+        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC>(a, bx, by, t, lds);
+        rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
     }
 }
-template <int V, int LOGM, bool STRIDED, bool INVERSE, int I, int SEND>
+template <int V, int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int SEND>
 static void rounds_inv(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (I >= 0) {
         constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true>(a, bx, by, t, lds);
-        rounds_inv<V, LOGM, STRIDED, INVERSE, I - 1, SEND - RHO>(a, bx, by, lds);
+        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, false, CC>(a, bx, by, t, lds);
+        rounds_inv<V, LOGM, STRIDED, INVERSE, CC, I - 1, SEND - RHO>(a, bx, by, lds);
     }
 }
-template <int V, int LOGM, bool STRIDED, bool INVERSE>
+template <int V, int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 static void pass_emu(const NttArgs &a, int gx, int gy)
 {
+    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile<V>::LOG - LOGM : -1;
 #pragma omp parallel
     {
         std::vector<u64> lds(NttLds<V>::ELEMS);
 #pragma omp for collapse(2)
         for (int by = 0; by < gy; by++)
             for (int bx = 0; bx < gx; bx++) {
-                for (int t = 0; t < NTT_THREADS; t++) ntt_body_load<STRIDED, INVERSE>(a, bx, by, t, lds.data());
+                for (int t = 0; t < NTT_THREADS; t++) ntt_body_load<STRIDED, INVERSE, CM, CC>(a, bx, by, t, lds.data());
                 if constexpr (!INVERSE) {
-                    if (a.lazy8) rounds_fwd<V, LOGM, STRIDED, INVERSE, 0, 0, true>(a, bx, by, lds.data());
-                    else rounds_fwd<V, LOGM, STRIDED, INVERSE, 0, 0, false>(a, bx, by, lds.data());
+                    if (a.lazy8) rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, 0, 0, true>(a, bx, by, lds.data());
+                    else rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, 0, 0, false>(a, bx, by, lds.data());
                 }
-                else rounds_inv<V, LOGM, STRIDED, INVERSE, NttSchedV<V, LOGM>::R - 1, LOGM>(a, bx, by, lds.data());
-                for (int t = 0; t < NTT_THREADS; t++) ntt_body_store<STRIDED, INVERSE>(a, bx, by, t, lds.data());
+                else rounds_inv<V, LOGM, STRIDED, INVERSE, CC, NttSchedV<V, LOGM>::R - 1, LOGM>(a, bx, by, lds.data());
+                for (int t = 0; t < NTT_THREADS; t++) ntt_body_store<STRIDED, INVERSE, CM, CC>(a, bx, by, t, lds.data());
             }
     }
 }
@@ -77,11 +78,10 @@ static void launch_pass_v(NttArgs a, int logm, int other)
     if (logc > other) logc = other;
     a.logc = logc;
     const int gx = 1 << (other - logc), gy = a.count;
+    const bool full = logc == NttTile<V>::LOG - logm;
+#define PASS_EMU(M_) case M_: if (full) pass_emu<V, M_, STRIDED, INVERSE, true>(a, gx, gy); else pass_emu<V, M_, STRIDED, INVERSE, false>(a, gx, gy); break;
     switch (logm) {
-    case 5: pass_emu<V, 5, STRIDED, INVERSE>(a, gx, gy); break;
-    case 6: pass_emu<V, 6, STRIDED, INVERSE>(a, gx, gy); break;
-    case 7: pass_emu<V, 7, STRIDED, INVERSE>(a, gx, gy); break;
-    case 8: pass_emu<V, 8, STRIDED, INVERSE>(a, gx, gy); break;
+    PASS_EMU(5) PASS_EMU(6) PASS_EMU(7) PASS_EMU(8)
     default: fprintf(stderr, "emu: unsupported pass size\n"); abort();
     }
 }
