@@ -213,6 +213,14 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                 }
             }
         } else {
+            // Inverse (GS) butterflies X' = X + Y, Y' = (X - Y) w.  The product leaves the Shoup multiplication in [0,2q) whatever
+            // its input, so only the sums grow, doubling per stage.  Harvey folds every sum back below 2q.  LAZY8 (16q <= 2^64)
+            // tracks the bound of each of the thread's values as a compile-time multiple of q (bnd[]; the butterfly pattern of a
+            // register round is fixed), folds a sum only when it would reach 16q, and restores the [0,2q) invariant once at the
+            // end of the round: 16 instead of 32 conditional subtractions per radix-16 round.
+            int bnd[RAD];
+#pragma unroll
+            for (int k = 0; k < RAD; k++) bnd[k] = 2;
 #pragma unroll
             for (int u = RHO - 1; u >= 0; u--) {
                 const int half = 1 << (RHO - 1 - u);
@@ -225,10 +233,30 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                         const int k0 = b * 2 * half + j, k1 = k0 + half;
                         const u64 x = v[k0], y = v[k1];
                         u64 s = x + y;
-                        s -= (s >= q2) ? q2 : 0;
-                        v[k0] = s;
-                        v[k1] = shoup_lazy(x + q2 - y, w, ws, q);
+                        if (LAZY8) {
+                            int bs = bnd[k0] + bnd[k1];
+                            if (bs >= 16) {  // x, y < 8q each
+                                s -= (s >= q8) ? q8 : 0;
+                                bs = 8;
+                            }
+                            v[k0] = s;
+                            v[k1] = shoup_lazy(x + q * (u64)bnd[k1] - y, w, ws, q);  // + bnd q keeps the difference non-negative
+                            bnd[k0] = bs;
+                            bnd[k1] = 2;
+                        } else {
+                            s -= (s >= q2) ? q2 : 0;
+                            v[k0] = s;
+                            v[k1] = shoup_lazy(x + q2 - y, w, ws, q);
+                        }
                     }
+                }
+            }
+            if (LAZY8) {
+#pragma unroll
+                for (int k = 0; k < RAD; k++) {
+#pragma unroll
+                    for (int h = 8; h >= 2; h >>= 1)  // fold 16q -> 8q -> 4q -> 2q as far as this value's bound requires
+                        if (bnd[k] > h) { const u64 c = q * (u64)h; v[k] -= (v[k] >= c) ? c : 0; }
                 }
             }
         }

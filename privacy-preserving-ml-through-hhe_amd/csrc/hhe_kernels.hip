@@ -89,14 +89,14 @@ struct NttRounds {
             fwd<I + 1, S0 + RHO, LAZY8>(a, lds);
         }
     }
-    template <int I, int SEND>
+    template <int I, int SEND, bool LAZY8 = false>
     static __device__ __forceinline__ void inv(const NttArgs &a, u64 *lds)
     {
         if constexpr (I >= 0) {
             constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, false, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
             __syncthreads();
-            inv<I - 1, SEND - RHO>(a, lds);
+            inv<I - 1, SEND - RHO, LAZY8>(a, lds);
         }
     }
 };
@@ -115,7 +115,10 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
         if constexpr (!INVERSE) {
             if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, true>(a, lds);
             else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, false>(a, lds);
-        } else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM>(a, lds);
+        } else {
+            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM, true>(a, lds);
+            else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM, false>(a, lds);
+        }
     }
     ntt_body_store<STRIDED, INVERSE, CM, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
 }

@@ -41,13 +41,13 @@ static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
         rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
     }
 }
-template <int V, int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int SEND>
+template <int V, int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int SEND, bool LAZY8 = false>
 static void rounds_inv(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (I >= 0) {
         constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, false, CC>(a, bx, by, t, lds);
-        rounds_inv<V, LOGM, STRIDED, INVERSE, CC, I - 1, SEND - RHO>(a, bx, by, lds);
+        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC>(a, bx, by, t, lds);
+        rounds_inv<V, LOGM, STRIDED, INVERSE, CC, I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
     }
 }
 template <int V, int LOGM, bool STRIDED, bool INVERSE, bool FULL>
@@ -65,7 +65,8 @@ static void pass_emu(const NttArgs &a, int gx, int gy)
                     if (a.lazy8) rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, 0, 0, true>(a, bx, by, lds.data());
                     else rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, 0, 0, false>(a, bx, by, lds.data());
                 }
-                else rounds_inv<V, LOGM, STRIDED, INVERSE, CC, NttSchedV<V, LOGM>::R - 1, LOGM>(a, bx, by, lds.data());
+                else if (a.lazy8) rounds_inv<V, LOGM, STRIDED, INVERSE, CC, NttSchedV<V, LOGM>::R - 1, LOGM, true>(a, bx, by, lds.data());
+                else rounds_inv<V, LOGM, STRIDED, INVERSE, CC, NttSchedV<V, LOGM>::R - 1, LOGM, false>(a, bx, by, lds.data());
                 for (int t = 0; t < NTT_THREADS; t++) ntt_body_store<STRIDED, INVERSE, CM, CC>(a, bx, by, t, lds.data());
             }
     }
