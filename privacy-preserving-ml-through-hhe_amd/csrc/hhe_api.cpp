@@ -404,6 +404,12 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
         k_galois(ga, c->w->stream);
     }
     int cur = 0;
+    // The c0 branch of step i (96 polynomials per 32 items: it cannot fill the 1024 workgroup slots on its own) only feeds
+    // the c0 branch of step i+1, and like the digit transforms of step i+1 it depends on nothing later than the inverse
+    // transforms of step i: both go into one grid (k_ntt2_fwd).
+    const bool merge = c->merge_fwd && !side && !c->mac_fuse && !(c->digit_sub && c->digit_sub < B);
+    NttArgs k5;
+    bool k5_pending = false;
     for (int i = 0; i < PASTA_T - 1; ++i) {
         const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
         {   // digits T[I][J] = NTT_J(d[I] mod q_J) and S_k[J] = sum_I T[I][J] * key[I][k][J]; the I = J digit also feeds
@@ -423,7 +429,8 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
                     k_ntt_first_pass(a, false, c->w->stream);
                     k_digit_mac(a, m, c->w->stream);
                 } else {
-                    k_ntt(a, false, c->w->stream);
+                    if (k5_pending) { k_ntt2_fwd(k5, a, c->w->stream); k5_pending = false; }  // c0 branch of the previous step first: its long epilogue overlaps the digit tiles
+                    else k_ntt(a, false, c->w->stream);
                     k_ks_mac(m, c->w->stream);
                 }
             }
@@ -446,11 +453,13 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.aux_r = c->w->ws_S; a.acc = accp0;
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g;
             if (c->probe & 1) a.store_op = STORE_PLAIN;  // timing probe: price of the fused c0 epilogue (results invalid)
-            k_ntt(a, false, s5);
+            if (merge) { k5 = a; k5_pending = true; }  // launched in the grid of the next step's digit transforms
+            else k_ntt(a, false, s5);
             if (side) rt_event_record(lane.ev_k5[i & 1], s5);
         }
         cur ^= 1;
     }
+    if (k5_pending) k_ntt(k5, false, c->w->stream);
     if (side) rt_stream_wait_event(lane.stream, lane.ev_k5[(PASTA_T - 2) & 1]);
     const size_t shift = ((size_t)layer * PASTA_T + (PASTA_T - 1)) * ln;
     {   // last state: products only (a "virtual" rotation keeps the frame uniform)

@@ -313,6 +313,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     if (const char *e = getenv("HHE_GRAPH")) c->use_graphs = atoi(e);
     if (const char *e = getenv("HHE_MACFUSE")) c->mac_fuse = atoi(e);
     if (const char *e = getenv("HHE_LAZY8")) c->lazy8 = atoi(e);
+    if (const char *e = getenv("HHE_MERGE")) c->merge_fwd = atoi(e);
     if (const char *e = getenv("HHE_SIDE")) c->side_stream = atoi(e);
     if (const char *e = getenv("HHE_PIPE_PROBE")) c->probe = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);

@@ -63,6 +63,7 @@ struct hhe_ctx {
     size_t fc_chunk = 40;          // items per internal chunk of hhe_fc_row (0 = whole batch)
     size_t digit_sub = 0;          // >0: run the digit transforms + inner product in sub-batches of this many items (T stays cache resident)
     int mac_fuse = 0;              // fused digit-NTT row pass + key-switch inner product in the matmul loop
+    int merge_fwd = 1;             // fused matmul: the c0 branch of a step shares the grid of the next step's digit transforms (HHE_MERGE)
     int lazy8 = 1;                 // forward NTT rounds with one range fold per register round where the moduli allow it (HHE_LAZY8)
     int matmul_mode = 1;           // 1: fused 20-transform pipeline (default), 0: op-by-op schedule
     KsConsts ksc{};

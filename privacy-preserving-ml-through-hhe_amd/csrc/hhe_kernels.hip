@@ -80,26 +80,45 @@ struct NttRounds {
     static constexpr int R = NttSchedV<V, LOGM>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
     template <int I, int S0, bool LAZY8 = false>
-    static __device__ __forceinline__ void fwd(const NttArgs &a, u64 *lds)
+    static __device__ __forceinline__ void fwd(const NttArgs &a, int bx, int by, u64 *lds)
     {
         if constexpr (I < R) {
             constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC>(a, bx, by, threadIdx.x, lds);
             __syncthreads();
-            fwd<I + 1, S0 + RHO, LAZY8>(a, lds);
+            fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
         }
     }
     template <int I, int SEND, bool LAZY8 = false>
-    static __device__ __forceinline__ void inv(const NttArgs &a, u64 *lds)
+    static __device__ __forceinline__ void inv(const NttArgs &a, int bx, int by, u64 *lds)
     {
         if constexpr (I >= 0) {
             constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
-            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC>(a, bx, by, threadIdx.x, lds);
             __syncthreads();
-            inv<I - 1, SEND - RHO, LAZY8>(a, lds);
+            inv<I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
         }
     }
 };
+
+// one pass of one tile: load phase, register rounds through LDS, store phase
+template <int V, int LOGM, bool STRIDED, bool INVERSE, bool FULL>
+static __device__ __forceinline__ void ntt_pass_tile(const NttArgs &a, int bx, int by, u64 *lds)
+{
+    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile<V>::LOG - LOGM : -1;
+    ntt_body_load<STRIDED, INVERSE, CM, CC>(a, bx, by, threadIdx.x, lds);
+    __syncthreads();
+    if (!(a.probe & 4)) {  // probe bit 2: timing probe that skips the butterflies (memory pattern only)
+        if constexpr (!INVERSE) {
+            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, true>(a, bx, by, lds);
+            else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, false>(a, bx, by, lds);
+        } else {
+            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM, true>(a, bx, by, lds);
+            else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM, false>(a, bx, by, lds);
+        }
+    }
+    ntt_body_store<STRIDED, INVERSE, CM, CC>(a, bx, by, threadIdx.x, lds);
+}
 
 // V = 0: 4096-point tiles (bulk launches); V = 1: 2048-point tiles -- twice the workgroups, half the lifetime each,
 // used when a launch would not even fill the 1024 resident workgroup slots once (latency-bound small batches).
@@ -107,20 +126,25 @@ struct NttRounds {
 template <int V, int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
 {
-    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile<V>::LOG - LOGM : -1;
     __shared__ u64 lds[NttLds<V>::ELEMS];
-    ntt_body_load<STRIDED, INVERSE, CM, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
-    __syncthreads();
-    if (!(a.probe & 4)) {  // probe bit 2: timing probe that skips the butterflies (memory pattern only)
-        if constexpr (!INVERSE) {
-            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, true>(a, lds);
-            else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, false>(a, lds);
-        } else {
-            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM, true>(a, lds);
-            else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM, false>(a, lds);
-        }
-    }
-    ntt_body_store<STRIDED, INVERSE, CM, CC>(a, NTT_BX(a), NTT_BY(a), threadIdx.x, lds);
+    ntt_pass_tile<V, LOGM, STRIDED, INVERSE, FULL>(a, NTT_BX(a), NTT_BY(a), lds);
+}
+// Two independent batches of the same pass in ONE grid (polynomials [0, a1.count) use a1, the rest a2): a small batch
+// rides in the tail of a big one instead of paying a launch of its own that cannot fill the 1024 workgroup slots.
+// The argument block is selected per workgroup from the kernarg segment (uniform), the code is shared.
+template <int LOGM, bool STRIDED, bool FULL>
+__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass2_kernel(NttArgs a1, NttArgs a2)
+{
+    __shared__ u64 lds[NttLds<0>::ELEMS];
+    const int by = NTT_BY(a1);
+    const bool second = by >= a1.count;
+    // Selecting between the two by-value blocks would copy them to scratch; index the kernarg segment instead (a1 at
+    // offset 0, a2 right behind it), so every field stays a scalar load from constant memory.
+    typedef __attribute__((address_space(4))) const char *kernarg_ptr;
+    typedef __attribute__((address_space(4))) const NttArgs *args_ptr;
+    (void)a2;
+    const args_ptr pa = (args_ptr)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + (second ? sizeof(NttArgs) : 0));
+    ntt_pass_tile<0, LOGM, STRIDED, false, FULL>(*(const NttArgs *)pa, NTT_BX(a1), second ? by - a1.count : by, lds);
 }
 
 static int g_small_wgs = -1;
@@ -229,6 +253,38 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream s)
         launch_pass<false, true>(a, n2, n1, st);
         launch_pass<true, true>(a, n1, n2, st);
     }
+}
+
+template <bool STRIDED>
+static void launch_pass2(NttArgs a1, NttArgs a2, int logm, int other, hipStream_t st)
+{
+    int logc = NttTile<0>::LOG - logm;
+    if (logc > other) logc = other;
+    a1.logm = a2.logm = logm;
+    a1.logc = a2.logc = logc;
+    a1.tiles_log = a2.tiles_log = other - logc;
+    dim3 grid((unsigned)(((size_t)a1.count + a2.count) << a1.tiles_log));
+    const bool full = logc == NttTile<0>::LOG - logm;
+#define NTT_LAUNCH2(M_)                                                                                                   \
+    case M_:                                                                                                              \
+        if (full) hipLaunchKernelGGL((ntt_pass2_kernel<M_, STRIDED, true>), grid, dim3(NTT_THREADS), 0, st, a1, a2);      \
+        else hipLaunchKernelGGL((ntt_pass2_kernel<M_, STRIDED, false>), grid, dim3(NTT_THREADS), 0, st, a1, a2);          \
+        break;
+    switch (logm) {
+        NTT_LAUNCH2(5) NTT_LAUNCH2(6) NTT_LAUNCH2(7) NTT_LAUNCH2(8)
+    default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", logm); break;
+    }
+#undef NTT_LAUNCH2
+}
+// forward transforms of two batches (same N) in shared grids
+void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s)
+{
+    if (a1.count <= 0) { k_ntt(a2, false, s); return; }
+    if (a2.count <= 0) { k_ntt(a1, false, s); return; }
+    int n1, n2;
+    ntt_split(a1.logn, n1, n2);
+    launch_pass2<true>(a1, a2, n1, n2, (hipStream_t)s);
+    launch_pass2<false>(a1, a2, n2, n1, (hipStream_t)s);
 }
 
 // ---------------------------------------------------------------- element-wise family

@@ -168,6 +168,7 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream)
     if (!inverse) { launch_pass<true, false>(a, n1, n2); launch_pass<false, false>(a, n2, n1); }
     else { launch_pass<false, true>(a, n2, n1); launch_pass<true, true>(a, n1, n2); }
 }
+void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, false, s); k_ntt(a2, false, s); }
 #define LOOP(total, call)                                         \
     do {                                                          \
         const long long _t = (long long)(total);                  \
