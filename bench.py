@@ -128,12 +128,13 @@ def main():
     value = units / el_max
 
     # dominant kernel (ntt_pass_kernel) measured by itself with HIP events on the library's stream, in the launch mix
-    # of one rotation step of the pipeline at its chunk size: forward over the 32x12 digit polys, inverse over the
-    # 32x2 special limbs and the 32x3 c1 limbs, forward over the 32x3 c0 limbs -> 8 kernel launches (2 passes each)
+    # of one rotation step of the pipeline at its chunk size: forward over the 32x12 digit polys together with the 32x3
+    # c0 limbs of the previous step (one shared grid), inverse over the 32x2 special limbs and over the 32x3 c1 limbs
+    # -> 6 kernel launches (2 passes each)
     CH = 32
-    mix = [(CH * L * K, False), (CH * 2, True), (CH * L, True), (CH * L, False)]
+    mix = [(CH * L * K + CH * L, False), (CH * 2, True), (CH * L, True)]
     npoly = sum(m[0] for m in mix)
-    scratch = torch.zeros((CH * L * K, n), dtype=torch.int64, device=dev)
+    scratch = torch.zeros((CH * L * K + CH * L, n), dtype=torch.int64, device=dev)
     for cnt, inv in mix:
         X.ntt(scratch, cnt, 0, K, inv)
     torch.cuda.synchronize()
@@ -155,7 +156,7 @@ def main():
         A = a_block_bytes(n, L, K)
         path_ms = dev_ms / args.steps
         traffic = None  # HBM-side bytes per launch of the path from rocprofv3 PMC passes (tools/pmc_traffic.py)
-        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_b256_final.json")
+        tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic_b256_final2.json")
         if os.path.exists(tf) and args.params == "config2":
             traffic = json.load(open(tf))["traffic_bytes_per_transciphering"] * B
         achieved = A * B / (path_ms * 1e-3) / 1e9
@@ -169,10 +170,10 @@ def main():
                                    (f"MNIST-shaped: N=2^15, 4x60-bit, t=65537, batch-{B} blocks per GPU = 784-word samples x 7 block counters (last block 16 words)"),
                        "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256_final.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                         "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256_final2.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                          "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",
                          "algorithmic_bytes_per_unit": A, "units_per_launch": B, "launch_ms": path_ms,
-                         "dominant_kernel": {"name": "ntt_pass_kernel", "launch_mix": "one rotation step at chunk 32: fwd 384, inv 64, inv 96, fwd 96 polys (8 launches)",
+                         "dominant_kernel": {"name": "ntt_pass_kernel", "launch_mix": "one rotation step at chunk 32: fwd 480 (digits + c0 limbs, shared grid), inv 64, inv 96 polys (6 launches)",
                                              "algorithmic_bytes_per_launch": ntt_alg, "avg_launch_us": ntt_ms * 1e3,
                                              "achieved_GBps": ntt_alg / (ntt_ms * 1e-3) / 1e9,
                                              "frac": ntt_alg / (ntt_ms * 1e-3) / 1e9 / 8000.0}},

@@ -7,7 +7,7 @@ import collections, csv, glob, json, sys
 
 
 def load(d, name):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     per = collections.defaultdict(float)
     n = collections.Counter()
     for r in csv.DictReader(open(f)):
