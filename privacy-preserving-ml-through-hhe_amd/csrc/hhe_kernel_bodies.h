@@ -486,6 +486,74 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
     st2(a.S + ((b * 2 + 1) * a.K + J) * n + i, r1);
 }
 
+// The same inner product for a compile-time digit count LL <= 4 and a compile-time variant MODE (KS_PLAIN: write S;
+// KS_ACC: + diagonal product of the fused matmul; KS_PERM: shared digits read through the Galois index map + correction
+// table; KS_LEAF: KS_PERM with the data limbs summed into s_acc).  Straight-line code: every global load of the lane is
+// issued before the first dependent instruction, which is what a bandwidth-bound kernel at 4 waves/SIMD needs (the generic
+// body above makes L + 1 dependent round trips).
+enum { KS_PLAIN = 0, KS_ACC = 1, KS_PERM = 2, KS_LEAF = 3 };
+template <int LL, int MODE> HD void ks_mac_body_t(const KsMacArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = (gid & ((n >> 1) - 1)) << 1;
+    const size_t bj = gid >> (a.logn - 1);
+    const int J = (int)(bj % a.K);
+    const size_t b = bj / a.K;
+    if (b >= (size_t)a.B) return;
+    ModDev m;  // the three words the Barrett reductions need, fetched with the first wave of loads
+    m.q = a.mods[J].q; m.r_lo = a.mods[J].r_lo; m.r_hi = a.mods[J].r_hi;
+    constexpr bool PERM = MODE == KS_PERM || MODE == KS_LEAF;
+    u32 p0 = (u32)i;
+    if (PERM) p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt);
+    const bool diag = MODE == KS_ACC && J < LL, leaf = MODE == KS_LEAF && J < LL;
+    const u64 *dptr = diag ? a.mul_ptrs[b] : nullptr;  // pointer first: the operand load behind it is a dependent round trip
+    U2 t[LL], k0[LL], k1[LL];
+#pragma unroll
+    for (int I = 0; I < LL; I++) {
+        t[I] = ld2(a.T + ((b * LL + I) * a.K + J) * n + (PERM ? (size_t)(p0 & ~1u) : i));
+        k0[I] = ld2(a.key + (((size_t)I * 2 + 0) * a.K + J) * n + i);
+        k1[I] = ld2(a.key + (((size_t)I * 2 + 1) * a.K + J) * n + i);
+    }
+    U2 d = {0, 0}, accv = {0, 0}, e0 = {0, 0}, e1 = {0, 0}, c0 = {0, 0}, c1 = {0, 0};
+    u64 *ap = a.acc + (b * LL + J) * n + i;
+    u64 *q0 = a.s_acc + ((b * 2 + 0) * LL + J) * n + i, *q1 = a.s_acc + ((b * 2 + 1) * LL + J) * n + i;
+    if (diag) { d = ld2(dptr + a.mul_shift + (size_t)J * n + i); accv = ld2(ap); }
+    if (PERM) { e0 = ld2(a.corr + ((size_t)0 * a.K + J) * n + i); e1 = ld2(a.corr + ((size_t)1 * a.K + J) * n + i); }
+    if (leaf) { c0 = ld2(q0); c1 = ld2(q1); }
+    Acc128 s0[2] = {{e0.a, 0}, {e0.b, 0}}, s1[2] = {{e1.a, 0}, {e1.b, 0}};
+    U2 tj = t[0];
+#pragma unroll
+    for (int I = 0; I < LL; I++) {
+        if (PERM && (p0 & 1)) t[I] = U2{t[I].b, t[I].a};
+        if (I == J) tj = t[I];
+        acc_mac(s0[0], t[I].a, k0[I].a); acc_mac(s0[1], t[I].b, k0[I].b);
+        acc_mac(s1[0], t[I].a, k1[I].a); acc_mac(s1[1], t[I].b, k1[I].b);
+    }
+    const U2 r0 = {barrett128(s0[0].lo, s0[0].hi, m), barrett128(s0[1].lo, s0[1].hi, m)};
+    const U2 r1 = {barrett128(s1[0].lo, s1[0].hi, m), barrett128(s1[1].lo, s1[1].hi, m)};
+    if (diag) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product
+        accv.a = addmod(accv.a, mulmod(tj.a, d.a, m), m.q);
+        accv.b = addmod(accv.b, mulmod(tj.b, d.b, m), m.q);
+        st2(ap, accv);
+    }
+    if (leaf) {
+        c0.a = addmod(c0.a, r0.a, m.q); c0.b = addmod(c0.b, r0.b, m.q);
+        c1.a = addmod(c1.a, r1.a, m.q); c1.b = addmod(c1.b, r1.b, m.q);
+        st2(q0, c0); st2(q1, c1);
+        return;
+    }
+    st2(a.S + ((b * 2 + 0) * a.K + J) * n + i, r0);
+    st2(a.S + ((b * 2 + 1) * a.K + J) * n + i, r1);
+}
+// variant of a launch (-1: none of the specialisations applies, use the generic body)
+inline int ks_mac_mode(const KsMacArgs &a)
+{
+    if (a.L < 1 || a.L > 4) return -1;
+    if (a.perm_elt) return (a.corr && !a.acc) ? (a.s_acc ? KS_LEAF : KS_PERM) : -1;
+    if (a.s_acc || a.corr) return -1;
+    return a.acc ? KS_ACC : KS_PLAIN;
+}
+
 // gid over [2][K][N]
 HD void ks_corr_body(const KsCorrArgs &a, size_t gid)
 {

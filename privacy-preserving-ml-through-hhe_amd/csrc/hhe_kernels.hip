@@ -296,6 +296,7 @@ __global__ void __launch_bounds__(ELT_THREADS) elt_kernel(EltArgs a, int op) { e
 __global__ void __launch_bounds__(ELT_THREADS) galois_kernel(GaloisArgs a) { galois_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) perm_kernel(PermArgs a) { perm_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_mac_kernel(KsMacArgs a) { ks_mac_body(a, GID); }
+template <int LL, int MODE> __global__ void __launch_bounds__(ELT_THREADS) ks_mac_t_kernel(KsMacArgs a) { ks_mac_body_t<LL, MODE>(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_corr_kernel(KsCorrArgs a) { ks_corr_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_finish_kernel(KsFinishArgs a) { ks_finish_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) leaf_sum_kernel(LeafSumArgs a) { leaf_sum_body(a, GID); }
@@ -316,7 +317,28 @@ __global__ void __launch_bounds__(ELT_THREADS) behz_floor_kernel(BehzFloorArgs a
 void k_elt(const EltArgs &a, int op, rt_stream s) { LAUNCH1D(elt_kernel, (size_t)a.count << a.logn, s, a, op); }
 void k_galois(const GaloisArgs &a, rt_stream s) { LAUNCH1D(galois_kernel, (size_t)a.count << a.logn, s, a); }
 void k_perm(const PermArgs &a, rt_stream s) { LAUNCH1D(perm_kernel, (size_t)a.count << a.logn, s, a); }
-void k_ks_mac(const KsMacArgs &a, rt_stream s) { LAUNCH1D(ks_mac_kernel, ((size_t)a.B * a.K) << (a.logn - 1), s, a); }
+template <int MODE> static void launch_ks_mac_t(const KsMacArgs &a, rt_stream s)
+{
+    const size_t total = ((size_t)a.B * a.K) << (a.logn - 1);
+    switch (a.L) {
+    case 1: LAUNCH1D((ks_mac_t_kernel<1, MODE>), total, s, a); break;
+    case 2: LAUNCH1D((ks_mac_t_kernel<2, MODE>), total, s, a); break;
+    case 3: LAUNCH1D((ks_mac_t_kernel<3, MODE>), total, s, a); break;
+    default: LAUNCH1D((ks_mac_t_kernel<4, MODE>), total, s, a); break;
+    }
+}
+static int g_ks_generic = -1;
+void k_ks_mac(const KsMacArgs &a, rt_stream s)
+{
+    if (g_ks_generic < 0) { const char *e = getenv("HHE_KS_GENERIC"); g_ks_generic = e ? atoi(e) : 0; }  // A/B switch
+    switch (g_ks_generic ? -1 : ks_mac_mode(a)) {
+    case KS_PLAIN: launch_ks_mac_t<KS_PLAIN>(a, s); break;
+    case KS_ACC: launch_ks_mac_t<KS_ACC>(a, s); break;
+    case KS_PERM: launch_ks_mac_t<KS_PERM>(a, s); break;
+    case KS_LEAF: launch_ks_mac_t<KS_LEAF>(a, s); break;
+    default: LAUNCH1D(ks_mac_kernel, ((size_t)a.B * a.K) << (a.logn - 1), s, a); break;
+    }
+}
 void k_ks_corr(const KsCorrArgs &a, rt_stream s) { LAUNCH1D(ks_corr_kernel, ((size_t)2 * a.K) << a.logn, s, a); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream s) { LAUNCH1D(ks_finish_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s) { LAUNCH1D(leaf_sum_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }

@@ -177,7 +177,27 @@ void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, f
 void k_elt(const EltArgs &a, int op, rt_stream) { LOOP((size_t)a.count << a.logn, elt_body(a, op, (size_t)g)); }
 void k_galois(const GaloisArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, galois_body(a, (size_t)g)); }
 void k_perm(const PermArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, perm_body(a, (size_t)g)); }
-void k_ks_mac(const KsMacArgs &a, rt_stream) { LOOP(((size_t)a.B * a.K) << (a.logn - 1), ks_mac_body(a, (size_t)g)); }
+template <int MODE> static void ks_mac_t_emu(const KsMacArgs &a)
+{
+    const size_t total = ((size_t)a.B * a.K) << (a.logn - 1);
+    switch (a.L) {
+    case 1: LOOP(total, (ks_mac_body_t<1, MODE>(a, (size_t)g))); break;
+    case 2: LOOP(total, (ks_mac_body_t<2, MODE>(a, (size_t)g))); break;
+    case 3: LOOP(total, (ks_mac_body_t<3, MODE>(a, (size_t)g))); break;
+    default: LOOP(total, (ks_mac_body_t<4, MODE>(a, (size_t)g))); break;
+    }
+}
+void k_ks_mac(const KsMacArgs &a, rt_stream)
+{
+    const char *e = getenv("HHE_KS_GENERIC");
+    switch (e && atoi(e) ? -1 : ks_mac_mode(a)) {
+    case KS_PLAIN: ks_mac_t_emu<KS_PLAIN>(a); break;
+    case KS_ACC: ks_mac_t_emu<KS_ACC>(a); break;
+    case KS_PERM: ks_mac_t_emu<KS_PERM>(a); break;
+    case KS_LEAF: ks_mac_t_emu<KS_LEAF>(a); break;
+    default: LOOP(((size_t)a.B * a.K) << (a.logn - 1), ks_mac_body(a, (size_t)g)); break;
+    }
+}
 void k_ks_corr(const KsCorrArgs &a, rt_stream) { LOOP(((size_t)2 * a.K) << a.logn, ks_corr_body(a, (size_t)g)); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, ks_finish_body(a, (size_t)g)); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, leaf_sum_body(a, (size_t)g)); }
