@@ -42,12 +42,12 @@ def exported_symbols():
 
 def load_library(path=None):
     """Load the C-ABI library.  Default: the in-tree gfx950 build; anything else must be passed explicitly."""
-    path = path or LIB_PATH
+    path = path or os.environ.get("HHE_LIB") or LIB_PATH  # HHE_LIB: another gfx950 build of the same sources (A/B runs)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: the gfx950 HIP library is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    if os.path.abspath(path) == os.path.abspath(LIB_PATH):
+    if os.path.abspath(path) == os.path.abspath(LIB_PATH) or path == os.environ.get("HHE_LIB"):
         # Device memory and streams are shared with PyTorch-ROCm, so both must sit on ONE HIP runtime:
         # import torch first so libamdhip64.so.7 resolves to the copy torch already loaded (two HSA
         # runtimes in one process cannot both open the GPU).

@@ -265,13 +265,38 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
     }
 }
 
+// global operands of the fused store epilogues of one pair.  Fetched separately from their use so that a full tile can
+// put the loads of several pairs in flight before the first store (stores to acc / aux_out may alias them as far as the
+// compiler knows, which would otherwise serialise one memory round trip per pair).
+struct StorePre { U2 d, s, acc, gp; };
 template <bool STRIDED, bool INVERSE>
-HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 *dst, size_t pbase, int e2, const u64 *lds)
+HD StorePre ntt_store_fetch(const NttArgs &a, const NttGeom &g, size_t pbase, int gi)
+{
+    constexpr bool LAST = (STRIDED == INVERSE);
+    StorePre p = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    if (!LAST) return p;
+    if (INVERSE) {
+        if (a.store_op == STORE_KS1) p.s = ld2(a.aux_r + ((size_t)(g.poly / a.L) * 2 + 1) * g.n + gi);
+    } else if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
+        const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
+        p.d = ld2(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);
+        if (a.store_op == STORE_MAC) p.acc = ld2(a.acc + pbase + gi);
+    } else if (a.store_op == STORE_KS0) {
+        const int j = g.poly % a.L;
+        const size_t item = g.poly / a.L;
+        p.d = ld2(a.mul_ptrs[item] + a.mul_shift + (size_t)j * g.n + gi);
+        p.s = ld2(a.aux_r + ((item * 2 + 0) * a.K + j) * g.n + gi);
+        p.acc = ld2(a.acc + pbase + gi);
+        p.gp = ld2_perm(a.aux_in + pbase, (u32)gi, a.logn, a.gal_elt);
+    }
+    return p;
+}
+template <bool STRIDED, bool INVERSE>
+HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 *dst, size_t pbase, int gi, int l0, int l1,
+                       const StorePre &pre, const u64 *lds)
 {
     constexpr bool LAST = (STRIDED == INVERSE);
     const u64 q = m.q, q2 = q << 1;
-    int x, lane, gi, l0, l1;
-    ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
     u64 v[2] = {lds[l0], lds[l1]};
     if (a.store_op == 99) { if (v[0] == 0x123456789abcdefULL) dst[gi] = v[0]; return; }  // timing probe (no global write)
     if (!LAST || (!INVERSE && a.store_op == STORE_LAZY)) { st2(dst + gi, U2{v[0], v[1]}); return; }
@@ -295,9 +320,7 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
         }
         else if (a.store_op == STORE_KS1) {
             const int j = g.poly % a.L;
-            const size_t item = g.poly / a.L;
-            const U2 r = ld2(a.aux_r + (item * 2 + 1) * g.n + gi);
-            const u64 rr[2] = {r.a, r.b};
+            const u64 rr[2] = {pre.s.a, pre.s.b};
             for (int k = 0; k < 2; k++) {
                 u64 o = addmod(submod(v[k], reduce64(rr[k], m), q), a.ks.half_mod[j], q);
                 o = shoup_mul(o, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
@@ -323,12 +346,11 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
                 v[k] -= (v[k] >= q) ? q : 0;
             }
         if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
-            const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
-            const U2 d = ld2(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);
+            const U2 d = pre.d;
             v[0] = mulmod(v[0], d.a, m);
             v[1] = mulmod(v[1], d.b, m);
             if (a.store_op == STORE_MAC) {
-                U2 acc = ld2(a.acc + pbase + gi);
+                U2 acc = pre.acc;
                 acc.a = addmod(acc.a, v[0], q);
                 acc.b = addmod(acc.b, v[1], q);
                 st2(a.acc + pbase + gi, acc);
@@ -336,12 +358,9 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             }
         } else if (a.store_op == STORE_KS0) {
             const int j = g.poly % a.L;
-            const size_t item = g.poly / a.L;
-            const U2 d = ld2(a.mul_ptrs[item] + a.mul_shift + (size_t)j * g.n + gi);
-            const U2 s0 = ld2(a.aux_r + ((item * 2 + 0) * a.K + j) * g.n + gi);
-            U2 acc = ld2(a.acc + pbase + gi);
-            const U2 gp = ld2_perm(a.aux_in + pbase, (u32)gi, a.logn, a.gal_elt);
-            const u64 g0 = gp.a, g1 = gp.b;
+            const U2 d = pre.d, s0 = pre.s;
+            U2 acc = pre.acc;
+            const u64 g0 = pre.gp.a, g1 = pre.gp.b;
             acc.a = addmod(acc.a, mulmod(g0, d.a, m), q);
             acc.b = addmod(acc.b, mulmod(g1, d.b, m), q);
             st2(a.acc + pbase + gi, acc);
@@ -355,6 +374,29 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
     st2(dst + gi, U2{v[0], v[1]});
 }
 
+// NP pairs per lane, compile-time: the epilogue operands of G pairs are fetched before the first of them is stored (G > 1
+// trades registers for memory-level parallelism)
+template <bool STRIDED, bool INVERSE, int NP>
+HD void ntt_store_full(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 *dst, size_t pbase, int tid, const u64 *lds)
+{
+#ifndef NTT_STORE_G
+#define NTT_STORE_G 1  // measured on MI355X (in-call A/B, transcipherings/s): G=1 227, G=2 226, G=4 219 (the prefetched operands push the row pass past 128 VGPRs)
+#endif
+    constexpr int G = NTT_STORE_G;
+#pragma unroll
+    for (int k0 = 0; k0 < NP; k0 += G) {
+        StorePre pre[G];
+        int gi[G], l0[G], l1[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            int x, lane;
+            ntt_pair<STRIDED>(a, g, tid + (k0 + k) * NTT_THREADS, x, lane, gi[k], l0[k], l1[k]);
+            pre[k] = ntt_store_fetch<STRIDED, INVERSE>(a, g, pbase, gi[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < G; k++) ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, gi[k], l0[k], l1[k], pre[k], lds);
+    }
+}
 template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1>
 HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds)
 {
@@ -363,17 +405,14 @@ HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds
     u64 *dst = a.dst + (size_t)g.poly * g.n;
     const size_t pbase = (size_t)g.poly * g.n;
     const int E2 = (g.M * g.C) >> 1;
-    if (E2 == 8 * NTT_THREADS) {  // full tiles: constant trip count, unrolled
-#pragma unroll
-        for (int k = 0; k < 8; k++) ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, tid + k * NTT_THREADS, lds);
-        return;
+    if (E2 == 8 * NTT_THREADS) { ntt_store_full<STRIDED, INVERSE, 8>(a, g, m, dst, pbase, tid, lds); return; }  // full tiles
+    if (E2 == 4 * NTT_THREADS) { ntt_store_full<STRIDED, INVERSE, 4>(a, g, m, dst, pbase, tid, lds); return; }
+    for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) {
+        int x, lane, gi, l0, l1;
+        ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
+        const StorePre pre = ntt_store_fetch<STRIDED, INVERSE>(a, g, pbase, gi);
+        ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, gi, l0, l1, pre, lds);
     }
-    if (E2 == 4 * NTT_THREADS) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, tid + k * NTT_THREADS, lds);
-        return;
-    }
-    for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, e2, lds);
 }
 
 // ------------------------------------------------------------------ element-wise
