@@ -435,17 +435,19 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
                 }
             }
         }
-        {   // r_k = INTT(S_k[special]) + floor(q_sp/2)
+        {   // r_k = INTT(S_k[special]) + floor(q_sp/2), then c1 of the next state in coefficient form, already passed
+            // through the Galois map for the next digits (its mod-down epilogue reads r_1)
             NttArgs a = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, r, B * 2, K - 1, 1);
             a.src_item_polys = 1; a.src_item_stride = (size_t)K * n; a.store_op = STORE_RSP;
-            k_ntt(a, true, c->w->stream);
-            if (side) { rt_event_record(lane.ev_k4a[i & 1], lane.stream); rt_stream_wait_event(s5, lane.ev_k4a[i & 1]); }
-        }
-        {   // c1 of the next state, coefficient form, already passed through the Galois map for the next digits
-            NttArgs a = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
-            a.src_item_polys = L; a.src_item_stride = (size_t)2 * K * n; a.store_op = STORE_KS1;
-            a.aux_r = r; a.aux_out = c->w->ws_d; a.gal_elt = (c->probe & 2) ? 0 : g;  // probe bit 1: no Galois scatter (results invalid)
-            k_ntt(a, true, c->w->stream);
+            NttArgs a1 = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
+            a1.src_item_polys = L; a1.src_item_stride = (size_t)2 * K * n; a1.store_op = STORE_KS1;
+            a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = (c->probe & 2) ? 0 : g;  // probe bit 1: no Galois scatter (results invalid)
+            if (merge) k_ntt2_inv(a, a1, c->w->stream);
+            else {
+                k_ntt(a, true, c->w->stream);
+                if (side) { rt_event_record(lane.ev_k4a[i & 1], lane.stream); rt_stream_wait_event(s5, lane.ev_k4a[i & 1]); }
+                k_ntt(a1, true, c->w->stream);
+            }
         }
         {   // c0 of the next state in NTT form + permuted-frame product of the current c0
             NttArgs a = ntt_args(c, r, scr2, B * L, 0, L);

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
 // Two independent batches of the same pass in ONE grid (polynomials [0, a1.count) use a1, the rest a2): a small batch
 // rides in the tail of a big one instead of paying a launch of its own that cannot fill the 1024 workgroup slots.
 // The argument block is selected per workgroup from the kernarg segment (uniform), the code is shared.
-template <int LOGM, bool STRIDED, bool FULL>
+template <int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass2_kernel(NttArgs a1, NttArgs a2)
 {
     __shared__ u64 lds[NttLds<0>::ELEMS];
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass2_kernel(NttArgs a1, N
     typedef __attribute__((address_space(4))) const NttArgs *args_ptr;
     (void)a2;
     const args_ptr pa = (args_ptr)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + (second ? sizeof(NttArgs) : 0));
-    ntt_pass_tile<0, LOGM, STRIDED, false, FULL>(*(const NttArgs *)pa, NTT_BX(a1), second ? by - a1.count : by, lds);
+    ntt_pass_tile<0, LOGM, STRIDED, INVERSE, FULL>(*(const NttArgs *)pa, NTT_BX(a1), second ? by - a1.count : by, lds);
 }
 
 static int g_small_wgs = -1;
@@ -255,7 +255,7 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream s)
     }
 }
 
-template <bool STRIDED>
+template <bool STRIDED, bool INVERSE>
 static void launch_pass2(NttArgs a1, NttArgs a2, int logm, int other, hipStream_t st)
 {
     int logc = NttTile<0>::LOG - logm;
@@ -267,8 +267,8 @@ static void launch_pass2(NttArgs a1, NttArgs a2, int logm, int other, hipStream_
     const bool full = logc == NttTile<0>::LOG - logm;
 #define NTT_LAUNCH2(M_)                                                                                                   \
     case M_:                                                                                                              \
-        if (full) hipLaunchKernelGGL((ntt_pass2_kernel<M_, STRIDED, true>), grid, dim3(NTT_THREADS), 0, st, a1, a2);      \
-        else hipLaunchKernelGGL((ntt_pass2_kernel<M_, STRIDED, false>), grid, dim3(NTT_THREADS), 0, st, a1, a2);          \
+        if (full) hipLaunchKernelGGL((ntt_pass2_kernel<M_, STRIDED, INVERSE, true>), grid, dim3(NTT_THREADS), 0, st, a1, a2);      \
+        else hipLaunchKernelGGL((ntt_pass2_kernel<M_, STRIDED, INVERSE, false>), grid, dim3(NTT_THREADS), 0, st, a1, a2);          \
         break;
     switch (logm) {
         NTT_LAUNCH2(5) NTT_LAUNCH2(6) NTT_LAUNCH2(7) NTT_LAUNCH2(8)
@@ -283,8 +283,20 @@ void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s)
     if (a2.count <= 0) { k_ntt(a1, false, s); return; }
     int n1, n2;
     ntt_split(a1.logn, n1, n2);
-    launch_pass2<true>(a1, a2, n1, n2, (hipStream_t)s);
-    launch_pass2<false>(a1, a2, n2, n1, (hipStream_t)s);
+    launch_pass2<true, false>(a1, a2, n1, n2, (hipStream_t)s);
+    launch_pass2<false, false>(a1, a2, n2, n1, (hipStream_t)s);
+}
+// inverse transforms of two batches where the store epilogue of the SECOND may read results of the first: the row passes
+// (no such dependency yet) share one grid, the strided passes run one after the other
+void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s)
+{
+    if (a1.count <= 0 || a2.count <= 0) { k_ntt(a1, true, s); k_ntt(a2, true, s); return; }
+    int n1, n2;
+    ntt_split(a1.logn, n1, n2);
+    hipStream_t st = (hipStream_t)s;
+    launch_pass2<false, true>(a1, a2, n2, n1, st);
+    launch_pass<true, true>(a1, n1, n2, st);
+    launch_pass<true, true>(a2, n1, n2, st);
 }
 
 // ---------------------------------------------------------------- element-wise family

@@ -35,6 +35,8 @@ const char *rt_last_error();
 void k_ntt(const NttArgs &a, bool inverse, rt_stream s);  // runs both passes; a.logm/logc ignored
 // forward transforms of two independent batches of the same degree in shared grids (the second one rides in the tail of the first)
 void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s);
+// inverse transforms of two batches; the store epilogue of the second may read the results of the first (row passes share a grid)
+void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s);
 void k_ntt_first_pass(const NttArgs &a, bool inverse, rt_stream s);  // only the first pass (intermediate left in a.dst)
 // fused: row pass of the forward digit NTTs (after k_ntt_first_pass into a.dst = T) + key-switch inner product into m.S
 void k_digit_mac(const NttArgs &a, const KsMacArgs &m, rt_stream s);

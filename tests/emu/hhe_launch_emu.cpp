@@ -169,6 +169,7 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream)
     else { launch_pass<false, true>(a, n2, n1); launch_pass<true, true>(a, n1, n2); }
 }
 void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, false, s); k_ntt(a2, false, s); }
+void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, true, s); k_ntt(a2, true, s); }
 #define LOOP(total, call)                                         \
     do {                                                          \
         const long long _t = (long long)(total);                  \
