@@ -173,8 +173,9 @@ def main():
                          "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256_final2.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                          "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",
                          "algorithmic_bytes_per_unit": A, "units_per_launch": B, "launch_ms": path_ms,
-                         "dominant_kernel": {"name": "ntt_pass_kernel", "launch_mix": "one rotation step at chunk 32: fwd 480 (digits + c0 limbs, shared grid), inv 64, inv 96 polys (6 launches)",
+                         "dominant_kernel": {"name": "ntt_pass_kernel", "launch_mix": "one rotation step at chunk 32 through hhe_ntt: fwd 480 (digits + c0 limbs), inv 64, inv 96 polys = 6 launches (the pipeline itself shares the inverse row pass: 5 launches)",
                                              "algorithmic_bytes_per_launch": ntt_alg, "avg_launch_us": ntt_ms * 1e3,
+                                             "us_per_polynomial": ntt_ms * 1e3 * launches / npoly,
                                              "achieved_GBps": ntt_alg / (ntt_ms * 1e-3) / 1e9,
                                              "frac": ntt_alg / (ntt_ms * 1e-3) / 1e9 / 8000.0}},
         }
