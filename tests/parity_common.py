@@ -58,6 +58,23 @@ def check_ntt(X, O, mem, seed=0):
     assert (mem.to_host(d) == ref).all()
     X.ntt(d, nm + 1, 0, nm + 1, True)
     assert (mem.to_host(d) == polys).all()
+    # extreme residues: the lazily reduced butterflies (values allowed to grow to 16q between folds) must not wrap 64 bits
+    mods = [O.q[i] if i < O.K else O.query("bsk", i - O.K) for i in range(nm)] + [O.t]
+    for pattern in ("max", "alt", "one_hot"):
+        ext = np.zeros((nm + 1, O.n), np.uint64)
+        for i, qi in enumerate(mods):
+            if pattern == "max":
+                ext[i, :] = qi - 1
+            elif pattern == "alt":
+                ext[i, ::2] = qi - 1
+            else:
+                ext[i, O.n - 1] = qi - 1
+        ref = np.stack([O.ntt_fwd(i, ext[i]) for i in range(nm)] + [O.ntt_fwd(-1, ext[nm])])
+        d = mem.to_dev(ext)
+        X.ntt(d, nm + 1, 0, nm + 1, False)
+        assert (mem.to_host(d) == ref).all(), pattern
+        X.ntt(d, nm + 1, 0, nm + 1, True)
+        assert (mem.to_host(d) == ext).all(), pattern
 
 
 def check_ops(X, S, mem, B=3, seed=0):
