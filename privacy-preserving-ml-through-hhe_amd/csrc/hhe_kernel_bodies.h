@@ -79,6 +79,35 @@ template <bool STRIDED> HD int ntt_gidx(const NttGeom &g, int x, int lane)
 struct alignas(16) U2 { u64 a, b; };
 HD U2 ld2(const u64 *p) { return *reinterpret_cast<const U2 *>(p); }   // 16 B per lane: the coalescing sweet spot
 HD void st2(u64 *p, U2 v) { *reinterpret_cast<U2 *>(p) = v; }
+// Streaming variants for data that is written once and read by a later kernel / read once.  NTT_NT bits, measured in-call on
+// MI355X (transcipherings/s, default 1): 1 = non-temporal stores of the transform outputs (intermediate, lazy digits T):
+// 229 vs 223 without; 2 = non-temporal transform loads: neutral; 4 = inner-product output S: -1 %; 8 = c0-branch output: neutral.
+#ifndef NTT_NT
+#define NTT_NT 1
+#endif
+template <int BIT = 1> HD void st2_stream(u64 *p, U2 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NTT_NT & BIT) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 w; w.x = v.a; w.y = v.b;
+        __builtin_nontemporal_store(w, reinterpret_cast<u64x2 *>(p));
+        return;
+    }
+#endif
+    st2(p, v);
+}
+HD U2 ld2_stream(const u64 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NTT_NT & 2) {
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 w = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(p));
+        return U2{w.x, w.y};
+    }
+#endif
+    return ld2(p);
+}
 // (in[pi(x)], in[pi(x+1)]) for even x with one 16-byte load: x and x+1 differ in the top bit of their bit reversal, the
 // odd exponents 2*bitrev+1 then differ by N, so do their products with the (odd) Galois element, hence pi(x+1) = pi(x) ^ 1
 HD U2 ld2_perm(const u64 *base, u32 x_even, int logn, u32 elt)
@@ -129,7 +158,7 @@ HD void ntt_load_full(const NttArgs &a, const NttGeom &g, const ModDev &m, const
         int x, lane, gi;
         ntt_pair<STRIDED>(a, g, tid + k * NTT_THREADS, x, lane, gi, l0[k], l1[k]);
         if (FIRST && a.load_op == 99) { v[k].a = (u64)(x * 131 + lane); v[k].b = v[k].a + 1; }  // timing probe (no global read)
-        else v[k] = ld2(src + gi);
+        else v[k] = ld2_stream(src + gi);
     }
 #pragma unroll
     for (int k = 0; k < NP; k++) {
@@ -299,7 +328,7 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
     const u64 q = m.q, q2 = q << 1;
     u64 v[2] = {lds[l0], lds[l1]};
     if (a.store_op == 99) { if (v[0] == 0x123456789abcdefULL) dst[gi] = v[0]; return; }  // timing probe (no global write)
-    if (!LAST || (!INVERSE && a.store_op == STORE_LAZY)) { st2(dst + gi, U2{v[0], v[1]}); return; }
+    if (!LAST || (!INVERSE && a.store_op == STORE_LAZY)) { st2_stream(dst + gi, U2{v[0], v[1]}); return; }
     if (INVERSE) {
         const bool st = a.store_op == STORE_SCALE_T;
         for (int k = 0; k < 2; k++) {
@@ -367,7 +396,7 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             U2 o;
             o.a = addmod(g0, shoup_mul(submod(s0.a, v[0], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
             o.b = addmod(g1, shoup_mul(submod(s0.b, v[1], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
-            st2(a.aux_out + pbase + gi, o);
+            st2_stream<8>(a.aux_out + pbase + gi, o);
             return;
         }
     }
@@ -581,8 +610,8 @@ template <int LL, int MODE> HD void ks_mac_body_t(const KsMacArgs &a, size_t gid
         st2(q0, c0); st2(q1, c1);
         return;
     }
-    st2(a.S + ((b * 2 + 0) * a.K + J) * n + i, r0);
-    st2(a.S + ((b * 2 + 1) * a.K + J) * n + i, r1);
+    st2_stream<4>(a.S + ((b * 2 + 0) * a.K + J) * n + i, r0);
+    st2_stream<4>(a.S + ((b * 2 + 1) * a.K + J) * n + i, r1);
 }
 // variant of a launch (-1: none of the specialisations applies, use the generic body)
 inline int ks_mac_mode(const KsMacArgs &a)
