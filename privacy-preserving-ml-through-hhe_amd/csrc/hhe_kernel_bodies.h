@@ -81,7 +81,8 @@ HD U2 ld2(const u64 *p) { return *reinterpret_cast<const U2 *>(p); }   // 16 B p
 HD void st2(u64 *p, U2 v) { *reinterpret_cast<U2 *>(p) = v; }
 // Streaming variants for data that is written once and read by a later kernel / read once.  NTT_NT bits, measured in-call on
 // MI355X (transcipherings/s, default 1): 1 = non-temporal stores of the transform outputs (intermediate, lazy digits T):
-// 229 vs 223 without; 2 = non-temporal transform loads: neutral; 4 = inner-product output S: -1 %; 8 = c0-branch output: neutral.
+// 229 vs 223 without; 2 = non-temporal transform loads: neutral; 4 = inner-product output S: -1 %; 8 = c0-branch output: neutral;
+// 16 / 32 = non-temporal loads of T / of the diagonal operand in the inner product: neutral.
 #ifndef NTT_NT
 #define NTT_NT 1
 #endif
@@ -97,10 +98,10 @@ template <int BIT = 1> HD void st2_stream(u64 *p, U2 v)
 #endif
     st2(p, v);
 }
-HD U2 ld2_stream(const u64 *p)
+template <int BIT = 2> HD U2 ld2_stream(const u64 *p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (NTT_NT & 2) {
+    if (NTT_NT & BIT) {
         typedef u64 u64x2 __attribute__((ext_vector_type(2)));
         const u64x2 w = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(p));
         return U2{w.x, w.y};
@@ -578,14 +579,14 @@ template <int LL, int MODE> HD void ks_mac_body_t(const KsMacArgs &a, size_t gid
     U2 t[LL], k0[LL], k1[LL];
 #pragma unroll
     for (int I = 0; I < LL; I++) {
-        t[I] = ld2(a.T + ((b * LL + I) * a.K + J) * n + (PERM ? (size_t)(p0 & ~1u) : i));
+        t[I] = ld2_stream<16>(a.T + ((b * LL + I) * a.K + J) * n + (PERM ? (size_t)(p0 & ~1u) : i));
         k0[I] = ld2(a.key + (((size_t)I * 2 + 0) * a.K + J) * n + i);
         k1[I] = ld2(a.key + (((size_t)I * 2 + 1) * a.K + J) * n + i);
     }
     U2 d = {0, 0}, accv = {0, 0}, e0 = {0, 0}, e1 = {0, 0}, c0 = {0, 0}, c1 = {0, 0};
     u64 *ap = a.acc + (b * LL + J) * n + i;
     u64 *q0 = a.s_acc + ((b * 2 + 0) * LL + J) * n + i, *q1 = a.s_acc + ((b * 2 + 1) * LL + J) * n + i;
-    if (diag) { d = ld2(dptr + a.mul_shift + (size_t)J * n + i); accv = ld2(ap); }
+    if (diag) { d = ld2_stream<32>(dptr + a.mul_shift + (size_t)J * n + i); accv = ld2(ap); }
     if (PERM) { e0 = ld2(a.corr + ((size_t)0 * a.K + J) * n + i); e1 = ld2(a.corr + ((size_t)1 * a.K + J) * n + i); }
     if (leaf) { c0 = ld2(q0); c1 = ld2(q1); }
     Acc128 s0[2] = {{e0.a, 0}, {e0.b, 0}}, s1[2] = {{e1.a, 0}, {e1.b, 0}};
