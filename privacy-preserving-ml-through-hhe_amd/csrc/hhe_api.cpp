@@ -414,7 +414,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     for (int i = 0; i < PASTA_T - 1; ++i) {
         const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
         {   // digits T[I][J] = NTT_J(d[I] mod q_J) and S_k[J] = sum_I T[I][J] * key[I][k][J]; the I = J digit also feeds
-            // the plain product.  Fused: the row pass keeps S in registers and never writes T.
+            // the plain product (HHE_MACFUSE=1: the row pass keeps S in registers and never writes T).
             const size_t sub = (c->digit_sub && c->digit_sub < B) ? c->digit_sub : B;
             for (size_t o = 0; o < B; o += sub) {
                 const size_t bs = std::min(sub, B - o);
