@@ -28,12 +28,8 @@ NttArgs ntt_args(const hhe_ctx *c, const u64 *src, u64 *dst, size_t count, int m
     a.mod_base = mod_base; a.mod_cycle = mod_cycle; a.src_div = 1; a.t = c->t;
     a.load_op = LOAD_PLAIN; a.store_op = STORE_PLAIN; a.mul_cycle = 1; a.mul_item_polys = 1;
     a.L = c->L; a.K = c->K; a.ks = c->ksc;
-    a.lazy8 = c->lazy8;
+    a.lazy8 = ntt_lazy8(c, mod_base, mod_cycle);
     if (c->probe & 4) a.probe = 4;  // HHE_PIPE_PROBE bit 2: skip the butterflies (memory pattern + epilogues only; results invalid)
-    for (int i = mod_base; i < mod_base + mod_cycle && a.lazy8; ++i) {
-        const u64 mv = i < c->K ? c->q[i] : (i <= c->K + c->L ? c->bsk[i - c->K] : c->t);
-        if (mv >> 60) a.lazy8 = 0;  // 16q must fit 64 bits (SEAL's own primes are at most 60 bits; the BEHZ base has 61)
-    }
     return a;
 }
 void op_ntt(hhe_ctx *c, u64 *polys, size_t count, int mod_base, int mod_cycle, bool inverse, int store_op = STORE_PLAIN)

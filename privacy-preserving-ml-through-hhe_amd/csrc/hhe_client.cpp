@@ -89,7 +89,7 @@ extern "C" int hhe_decrypt(hhe_ctx *c, const uint64_t *sk, const uint64_t *ct, s
     a.src = ct + ln; a.dst = c1s.w(); a.mods = c->d_mods; a.logn = c->logn; a.count = (int)(B * L);
     a.mod_base = 0; a.mod_cycle = L; a.src_div = 1; a.src_item_polys = L; a.src_item_stride = 2 * ln; a.t = c->t;
     a.load_op = LOAD_PLAIN; a.store_op = STORE_MUL; a.mul = dsk.w(); a.mul_cycle = L; a.mul_item_polys = 1;
-    a.L = L; a.K = c->K; a.ks = c->ksc;
+    a.L = L; a.K = c->K; a.ks = c->ksc; a.lazy8 = ntt_lazy8(c, 0, L);
     k_ntt(a, false, st);
     NttArgs inv = a;
     inv.src = c1s.w(); inv.src_item_polys = 0; inv.src_item_stride = 0; inv.store_op = STORE_PLAIN; inv.mul = nullptr;
@@ -129,7 +129,7 @@ extern "C" int hhe_decrypt(hhe_ctx *c, const uint64_t *sk, const uint64_t *ct, s
     memset(&p, 0, sizeof(p));
     p.src = plain.w(); p.dst = plain.w(); p.mods = c->d_mods; p.logn = c->logn; p.count = (int)B;
     p.mod_base = c->mod_t; p.mod_cycle = 1; p.src_div = 1; p.t = c->t; p.mul_cycle = 1; p.mul_item_polys = 1;
-    p.L = L; p.K = c->K; p.ks = c->ksc;
+    p.L = L; p.K = c->K; p.ks = c->ksc; p.lazy8 = ntt_lazy8(c, c->mod_t, 1);
     k_ntt(p, false, st);
     DecodeArgs g2;
     g2.in = plain.w(); g2.vals = vals; g2.slot_map = c->d_slot_map; g2.logn = c->logn; g2.B = B;

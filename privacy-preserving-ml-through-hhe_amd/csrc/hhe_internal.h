@@ -114,5 +114,17 @@ u32 galois_elt_from_step(const hhe_ctx *c, int step);
 // PASTA-3 public randomness (hhe_pasta_public.cpp)
 void pasta3_block_randomness(u64 t, u64 nonce, u64 block, u64 *mats, u64 *rcs);
 
+// 1 when every modulus of an NTT launch over ModDev indices [mod_base, mod_base + mod_cycle) is below 2^60 (16q fits 64 bits):
+// the kernels may then fold the butterfly ranges once per register round (NttArgs::lazy8)
+inline int ntt_lazy8(const hhe_ctx *c, int mod_base, int mod_cycle)
+{
+    if (!c->lazy8) return 0;
+    for (int i = mod_base; i < mod_base + mod_cycle; ++i) {
+        const u64 mv = i < c->K ? c->q[i] : (i <= c->K + c->L ? c->bsk[i - c->K] : c->t);
+        if (mv >> 60) return 0;  // SEAL's own primes are at most 60 bits; the BEHZ base has 61
+    }
+    return 1;
+}
+
 void hhe_set_error(const std::string &msg);
 int lane_reserve(hhe_ctx *c, Lane &ln, size_t B);
