@@ -128,7 +128,9 @@ int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key_dptr, const uint64_t *reco
  * default_galois_only != 0 makes rotate_rows see only the power-of-two Galois elements, i.e. behave as if called
  * with a GaloisKeys made by create_galois_keys() without arguments (what the CSP passes, CSP.cpp:312-316), even when
  * the context also holds flatten / PASTA keys.  The n-1 NAF rotation chains share prefixes and are evaluated as a
- * trie (identical ciphertext words, ~2.7x fewer key switches for n = 784). */
+ * trie (identical ciphertext words, ~2.7x fewer key switches for n = 784); the children of a trie node share the digit
+ * transforms of its c1 (exact unless a c1 coefficient is 0, in which case the chunk is recomputed with per-child transforms;
+ * hhe_ctx_query("fc_fallbacks") counts those).  Synchronous: returns when the results are in out. */
 int hhe_fc_row(hhe_ctx *c, const uint64_t *vi_dptr, const uint64_t *w_dptr, size_t W, size_t n_inputs, int relin_slot,
                int default_galois_only, uint64_t *out_dptr, size_t B);
 
