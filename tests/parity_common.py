@@ -239,3 +239,24 @@ def check_fc_variants(make_ctx, S, orc, mem, monkeypatch, n_in=37):
             assert (got[b] == refs[b]).all(), (shared, leafsum, b)
         assert X.query("fc_fallbacks") == ((B + int(chunk) - 1) // int(chunk) if shared == "2" else 0)
         X.close()
+
+
+def check_two_layer_chain(X, S, mem, n_in=24, seed=3):
+    """BASELINE config 4 shape (FC -> packed_square -> FC, SEAL_Cipher.cpp:547-552 between two sealhelper FC rows):
+    ciphertext parity of the whole chain against the oracle's op sequence."""
+    O = S.O
+    rng = np.random.default_rng(seed)
+    vi = O.encrypt(S.pk, O.encode(rng.integers(0, 4, n_in)), 61)
+    w1 = O.encrypt(S.pk, O.encode(rng.integers(0, 4, n_in)), 62)
+    w2 = O.encrypt(S.pk, O.encode(rng.integers(0, 4, n_in)), 63)
+    ref1, _ = O.fc_row(vi, w1, S.rk, S.gk, n_in)
+    ref_sq = O.relinearize(O.multiply(ref1, ref1), S.rk)
+    ref2, _ = O.fc_row(ref_sq, w2, S.rk, S.gk, n_in)
+    d1, d3, dsq, d2 = mem.empty((1,) + O.ct_shape), mem.empty((1, 3, O.L, O.n)), mem.empty((1,) + O.ct_shape), mem.empty((1,) + O.ct_shape)
+    X.fc_row(mem.to_dev(vi[None]), mem.to_dev(w1[None]), 1, n_in, d1, 1, relin_slot=0, default_galois_only=False)
+    X.multiply(d1, d1, d3, 1)
+    X.relinearize(d3, dsq, 1)
+    X.fc_row(dsq, mem.to_dev(w2[None]), 1, n_in, d2, 1, relin_slot=0, default_galois_only=False)
+    assert (mem.to_host(d1)[0] == ref1).all()
+    assert (mem.to_host(dsq)[0] == ref_sq).all()
+    assert (mem.to_host(d2)[0] == ref2).all()

@@ -326,3 +326,10 @@ def test_end_to_end_client_encrypt_csp_transcipher_analyst_decrypt(orc, api, lib
 def test_fc_row_shared_digit_variants(orc, api, lib, mem, monkeypatch):
     S = Setup(orc, 11, [60] * 4, all_galois=True)
     pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=lib), S, orc, mem, monkeypatch, n_in=100)
+
+
+def test_config4_two_layer_chain(orc, api, lib, mem):
+    S = Setup(orc, 12, [55] * 5, all_galois=True)
+    X = api.Context(S.logn, S.q, S.t, lib=lib)
+    S.load_keys(X)
+    pc.check_two_layer_chain(X, S, mem, n_in=128)

@@ -303,3 +303,10 @@ def test_analyst_batched_decrypt_matches_oracle(orc, api, emu_lib, mem, small):
 def test_fc_row_shared_digit_variants(orc, api, emu_lib, mem, monkeypatch):
     S = Setup(orc, 10, [50] * 4, all_galois=True)
     pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=emu_lib), S, orc, mem, monkeypatch)
+
+
+def test_config4_two_layer_chain(orc, api, emu_lib, mem):
+    S = Setup(orc, 10, [50] * 4, all_galois=True)
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    pc.check_two_layer_chain(X, S, mem)
