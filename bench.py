@@ -58,8 +58,11 @@ def main():
                     help="config2: N=2^15, 4x60-bit (BASELINE metric); default16384: the reference's defaults N=2^14, BFVDefault 9 primes")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-blocks-per-thread", type=int, default=2)
+    ap.add_argument("--graphs", type=int, default=1, choices=[0, 1],
+                    help="hipGraph replay of the matmul loop (library opt-in HHE_GRAPH=1: valid for transcipher-only processes like this one)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HHE_GRAPH", str(args.graphs))  # read by hhe_ctx_create
     import torch
     sh = importlib.import_module(PKG + ".sharding")
     api = importlib.import_module(PKG + ".api")
@@ -168,7 +171,8 @@ def main():
                                    ("BASELINE config 2: N=2^15, coeff_modulus 4x60-bit (L=3,K=4), t=65537, "
                                     f"batch-{B} independent 128-word PASTA-3 blocks per GPU, block counter 0") if args.workload == "config2" else
                                    (f"MNIST-shaped: N=2^15, 4x60-bit, t=65537, batch-{B} blocks per GPU = 784-word samples x 7 block counters (last block 16 words)"),
-                       "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective"},
+                       "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective",
+                       "graph_replay": os.environ.get("HHE_GRAPH", "0") == "1"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256_final2.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                          "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",

@@ -54,7 +54,8 @@ struct hhe_ctx {
     int nmod = 0;                  // K + (L+1) + 1
     int mod_t = 0;                 // index of the plain modulus
     int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
-    int use_graphs = 1;            // replay the fused matmul loop (1143 launches per layer) as a hipGraph on internal streams
+    int use_graphs = 0;            // HHE_GRAPH=1: replay the fused matmul loop as a hipGraph on the internal streams (+6 %).  Opt-in:
+                                   // on ROCm 7.2 replays go wrong after ~200 eager launches on other streams (hhe_kernels.hip)
     int side_stream = 0;           // overlap the off-critical-path c0 update (K5) with the next digit transforms
     int probe = 0;                 // HHE_PIPE_PROBE timing probes (bench only; results invalid when set)
     u64 fc_fallbacks = 0;          // how often the shared-digit path had to be recomputed exactly

@@ -57,17 +57,35 @@ int rt_capture_begin(rt_stream s)
     if (!s) return -1;  // the legacy default stream cannot be captured
     return rt_check(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
 }
+// The executable graph is kept together with the captured template (cheap, and independent of how much of the template the
+// runtime still references).  NOTE (ROCm 7.2 on gfx950, measured): after roughly 200-250 eager kernel launches on OTHER
+// streams of the process, replays of an instantiated graph compute wrong results (deterministically; a graph captured
+// afterwards is right again; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 avoids it at the price of the whole benefit).  Graph replay is
+// therefore opt-in (HHE_GRAPH=1) for processes that only transcipher; see DESIGN.md.
+struct RtGraph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
 void *rt_capture_end(rt_stream s)
 {
     hipGraph_t g = nullptr;
     if (rt_check(hipStreamEndCapture((hipStream_t)s, &g), "hipStreamEndCapture") || !g) return nullptr;
     hipGraphExec_t e = nullptr;
-    if (rt_check(hipGraphInstantiate(&e, g, nullptr, nullptr, 0), "hipGraphInstantiate")) e = nullptr;
-    (void)hipGraphDestroy(g);
-    return (void *)e;
+    if (rt_check(hipGraphInstantiate(&e, g, nullptr, nullptr, 0), "hipGraphInstantiate") || !e) {
+        (void)hipGraphDestroy(g);
+        return nullptr;
+    }
+    return (void *)new RtGraph{g, e};
 }
-int rt_graph_launch(void *exec, rt_stream s) { return rt_check(hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)s), "hipGraphLaunch"); }
-void rt_graph_destroy(void *exec) { if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec); }
+int rt_graph_launch(void *exec, rt_stream s) { return rt_check(hipGraphLaunch(((RtGraph *)exec)->exec, (hipStream_t)s), "hipGraphLaunch"); }
+void rt_graph_destroy(void *exec)
+{
+    if (!exec) return;
+    RtGraph *r = (RtGraph *)exec;
+    (void)hipGraphExecDestroy(r->exec);
+    (void)hipGraphDestroy(r->graph);
+    delete r;
+}
 
 // ---------------------------------------------------------------- NTT
 // one-dimensional grids (gridDim.y is limited to 65535 polynomials): block -> (tile, poly), tiles per poly = 2^tiles_log

@@ -143,10 +143,13 @@ def test_config1_dry_run_mnist_sample_end_to_end(orc, api, lib, mem):
     S.enc_key = O.encrypt(S.pk, O.pasta_pack_key(S.key), 11)
     X = api.Context(S.logn, S.q, S.t, lib=lib)
     S.load_keys(X)
-    rng = np.random.default_rng(7)
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mnist_1fc.json")))
     n_in = 784
-    pix = rng.integers(0, 4, n_in)            # 2-bit quantised image
-    w = rng.integers(-1, 2, n_in)             # ternary weight row
+    pix = np.array(fx["pixels"][0], dtype=np.int64)          # MNIST test image 0, 2-bit quantised (config 1 / 3 input)
+    W = np.array(fx["weights_rows"], dtype=np.int64)         # the reference's 1-layer integer weights, one row per neuron
+    w = W[0]
     cw, ncw = S.sym_blocks(orc, pix)
     nb = cw.shape[0]
     assert nb == 7 and ncw[-1] == 16
@@ -165,12 +168,30 @@ def test_config1_dry_run_mnist_sample_end_to_end(orc, api, lib, mem):
     dec = O.decode(O.decrypt(S.sk, mem.to_host(flat)[0]))
     assert (dec[:n_in] == pix).all()
     # FC row
-    wc = O.encrypt(S.pk, O.encode(w), 22)
+    wc = O.encrypt(S.pk, O.encode(w % T), 22)
     out = mem.empty((1,) + O.ct_shape)
     X.fc_row(flat, mem.to_dev(wc[None]), 1, n_in, out, 1)
     res = O.decode(O.decrypt(S.sk, mem.to_host(out)[0]))
     assert int(res[n_in - 1]) == int(np.dot(pix, w)) % T
     assert O.noise_budget(S.sk, mem.to_host(out)[0], 8) > 0
+    # the whole protocol on the device for the real sample: client PASTA encryption, CSP decompose, all 10 FC rows in one
+    # call, analyst decryption -- logits equal the plain integer layer, prediction equals the label
+    d_sym = mem.empty((1, n_in))
+    X.plain_crypt(S.key, mem.to_dev(pix.astype(np.uint64)[None]), 1, n_in, d_sym)
+    assert (mem.to_host(d_sym)[0] == orc.pasta_encrypt(T, S.key, pix)).all()
+    flat2 = mem.empty((1,) + O.ct_shape)
+    X.decompose(mem.to_dev(S.enc_key), mem.to_host(d_sym), flat2, mask_last=True)
+    assert (mem.to_host(flat2) == mem.to_host(flat)).all()
+    wcs = np.stack([O.encrypt(S.pk, O.encode(W[r] % T), 40 + r) for r in range(10)])
+    vi10 = mem.to_dev(np.repeat(mem.to_host(flat2), 10, axis=0))
+    out10 = mem.empty((10,) + O.ct_shape)
+    X.fc_row(vi10, mem.to_dev(wcs), 10, n_in, out10, 10)
+    vals = mem.empty((10, O.n))
+    X.decrypt(S.sk, out10, 10, vals)
+    got = mem.to_host(vals)[:, n_in - 1].astype(np.int64)
+    logits = np.where(got > (T + 1) // 2, got - T, got)
+    assert [int(v) for v in logits] == fx["plain_logits"][0]
+    assert int(np.argmax(logits)) == fx["labels"][0] == fx["argmax"][0]
 
 
 def test_config5_n65536_six_primes_rotation_chain_and_multiply(orc, api, lib, mem):
@@ -215,7 +236,7 @@ def test_babystep_giantstep_variant(orc, api, lib, mem):
 
 @pytest.mark.parametrize("knobs", [
     {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MACFUSE": "1"}, {"HHE_SIDE": "1"},
-    {"HHE_DIGIT_SUB": "1", "HHE_CHUNK": "4"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"}, {"HHE_GRAPH": "0"},
+    {"HHE_DIGIT_SUB": "1", "HHE_CHUNK": "4"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"}, {"HHE_GRAPH": "1"}, {"HHE_GRAPH": "1", "HHE_MERGE": "0"},
 ])
 def test_execution_knobs_are_result_neutral(orc, api, lib, mem, small, monkeypatch, knobs):
     pt = [(3 * i + 1) % 256 for i in range(300)]
@@ -333,3 +354,25 @@ def test_config4_two_layer_chain(orc, api, lib, mem):
     X = api.Context(S.logn, S.q, S.t, lib=lib)
     S.load_keys(X)
     pc.check_two_layer_chain(X, S, mem, n_in=128)
+
+
+def test_transcipher_unaffected_by_interleaved_eager_work(orc, api, lib, mem, small):
+    """CSP flow: transcipher, then hundreds of other launches (FC, packed ops), then transcipher again -- identical words.
+    (Guards the default execution mode; hipGraph replay, HHE_GRAPH=1, is opt-in because ROCm 7.2 replays go wrong after
+    ~200 eager launches on other streams, see DESIGN.md.)"""
+    X = api.Context(small.logn, small.q, small.t, lib=lib)
+    small.load_keys(X)
+    pt = [(5 * i + 2) % 256 for i in range(300)]
+    cw, ncw = small.sym_blocks(orc, pt)
+    nb = len(ncw)
+    first = mem.empty((nb,) + small.O.ct_shape)
+    X.transcipher(mem.to_dev(small.enc_key), cw, ncw, list(range(nb)), first)
+    ref = mem.to_host(first).copy()
+    d = mem.to_dev(ref[:1])
+    o = mem.empty((1,) + small.O.ct_shape)
+    for _ in range(400):
+        X.add(d, d, o, 1)
+    again = mem.empty((nb,) + small.O.ct_shape)
+    X.transcipher(mem.to_dev(small.enc_key), cw, ncw, list(range(nb)), again)
+    assert (mem.to_host(again) == ref).all()
+    assert (ref[0] == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[0, :ncw[0]], 0)).all()
