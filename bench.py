@@ -58,11 +58,12 @@ def main():
                     help="config2: N=2^15, 4x60-bit (BASELINE metric); default16384: the reference's defaults N=2^14, BFVDefault 9 primes")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-blocks-per-thread", type=int, default=2)
-    ap.add_argument("--graphs", type=int, default=1, choices=[0, 1],
-                    help="hipGraph replay of the matmul loop (library opt-in HHE_GRAPH=1: valid for transcipher-only processes like this one)")
+    ap.add_argument("--graphs", type=int, default=0, choices=[0, 1],
+                    help="1: hipGraph replay of the matmul loop (library opt-in HHE_GRAPH=1, valid for transcipher-only processes); 0: library default")
     args = ap.parse_args()
 
-    os.environ.setdefault("HHE_GRAPH", str(args.graphs))  # read by hhe_ctx_create
+    if args.graphs:
+        os.environ["HHE_GRAPH"] = "1"  # read by hhe_ctx_create
     import torch
     sh = importlib.import_module(PKG + ".sharding")
     api = importlib.import_module(PKG + ".api")
@@ -134,7 +135,7 @@ def main():
     # of one rotation step of the pipeline at its chunk size: forward over the 32x12 digit polys together with the 32x3
     # c0 limbs of the previous step (one shared grid), inverse over the 32x2 special limbs and over the 32x3 c1 limbs
     # -> 6 kernel launches (2 passes each)
-    CH = 32
+    CH = 128 if os.environ.get("HHE_GRAPH", "0") != "1" else 32  # the library's chunk size in this mode
     mix = [(CH * L * K + CH * L, False), (CH * 2, True), (CH * L, True)]
     npoly = sum(m[0] for m in mix)
     scratch = torch.zeros((CH * L * K + CH * L, n), dtype=torch.int64, device=dev)
@@ -177,7 +178,7 @@ def main():
                          "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256_final2.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                          "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",
                          "algorithmic_bytes_per_unit": A, "units_per_launch": B, "launch_ms": path_ms,
-                         "dominant_kernel": {"name": "ntt_pass_kernel", "launch_mix": "one rotation step at chunk 32 through hhe_ntt: fwd 480 (digits + c0 limbs), inv 64, inv 96 polys = 6 launches (the pipeline itself shares the inverse row pass: 5 launches)",
+                         "dominant_kernel": {"name": "ntt_pass_kernel", "launch_mix": f"one rotation step at chunk {CH} through hhe_ntt: fwd {CH * 15} (digits + c0 limbs), inv {CH * 2}, inv {CH * 3} polys = 6 launches (the pipeline itself shares the inverse row pass: 5 launches)",
                                              "algorithmic_bytes_per_launch": ntt_alg, "avg_launch_us": ntt_ms * 1e3,
                                              "us_per_polynomial": ntt_ms * 1e3 * launches / npoly,
                                              "achieved_GBps": ntt_alg / (ntt_ms * 1e-3) / 1e9,

@@ -95,7 +95,7 @@ struct hhe_ctx {
     Lane lanes[1 + HHE_MAX_STREAMS];
     Lane *w = &lanes[0];
     int nstreams = 2;      // internal streams used by hhe_pasta3_transcipher (0 = caller's stream only)
-    size_t chunk = 32;     // items per chunk: keeps a chunk's digit transforms inside the 256 MiB Infinity Cache
+    size_t chunk = 128;    // items per chunk (HHE_CHUNK): 128 for eager launching, 32 with graph replay (set in hhe_ctx_create)
     void *ev_fork = nullptr;
 
     size_t ct_words() const { return (size_t)2 * L * n; }
