@@ -686,7 +686,10 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
     } else {
         // independent chunks round-robin over the internal streams: a chunk's working set stays cache resident and
         // concurrent streams de-phase the load / butterfly / store phases of the transforms
-        const size_t per = std::min(B, c->chunk);
+        // balanced chunks: as many as the chunk size demands, rounded up to a multiple of the stream count
+        size_t nch = (B + c->chunk - 1) / c->chunk;
+        if (nch > 1) nch = (nch + ns - 1) / ns * ns;
+        const size_t per = (B + nch - 1) / nch;
         for (int s = 1; s <= ns && !rc; ++s) rc = lane_reserve(c, c->lanes[s], per);
         if (!rc) {
             rt_event_record(c->ev_fork, main.stream);
