@@ -1,4 +1,5 @@
 """Build libhhe_gfx950.so in-tree with hipcc (gfx950 only; cross-compiles without a GPU)."""
+import glob
 import os
 import subprocess
 
@@ -6,14 +7,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libhhe_gfx950.so")
 SOURCES = ["hhe_kernels.hip", "hhe_api.cpp", "hhe_context.cpp", "hhe_pasta_public.cpp", "hhe_client.cpp"]
-HEADERS = ["hhe_common.h", "hhe_modarith.h", "hhe_kernel_bodies.h", "hhe_launch.h", "hhe_internal.h"]
 
 
 def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "hhe_gfx950.h")]
+    deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.hip")) + \
+        glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -29,7 +29,6 @@ NttArgs ntt_args(const hhe_ctx *c, const u64 *src, u64 *dst, size_t count, int m
     a.load_op = LOAD_PLAIN; a.store_op = STORE_PLAIN; a.mul_cycle = 1; a.mul_item_polys = 1;
     a.L = c->L; a.K = c->K; a.ks = c->ksc;
     a.lazy8 = ntt_lazy8(c, mod_base, mod_cycle);
-    if (c->probe & 4) a.probe = 4;  // HHE_PIPE_PROBE bit 2: skip the butterflies (memory pattern + epilogues only; results invalid)
     return a;
 }
 void op_ntt(hhe_ctx *c, u64 *polys, size_t count, int mod_base, int mod_cycle, bool inverse, int store_op = STORE_PLAIN)
@@ -202,17 +201,19 @@ int ensure_feistel_mask(hhe_ctx *c)
     // mask_vec: ones on [1,128) and [N/2+1, N/2+128) (pasta_3_seal.cpp:230-235)
     std::vector<u64> vals(2 * PASTA_T, 1);
     vals[0] = 0; vals[PASTA_T] = 0;
-    u64 *dv = (u64 *)rt_malloc(vals.size() * 8), *pl = (u64 *)rt_malloc(n * 8);
-    c->d_feistel_mask = (u64 *)rt_malloc((size_t)c->L * n * 8);
-    if (!dv || !pl || !c->d_feistel_mask) return dev_fail("feistel mask alloc");
-    rt_h2d(dv, vals.data(), vals.size() * 8, c->w->stream);
-    op_encode(c, dv, 1, 2 * PASTA_T, PASTA_T, (int)half, pl);
-    op_lift_ntt(c, pl, 1, c->d_feistel_mask);
+    DevBuf dv(vals.size() * 8), pl(n * 8), mask((size_t)c->L * n * 8);
+    if (!dv.p || !pl.p || !mask.p) return dev_fail("feistel mask alloc");
+    rt_h2d(dv.p, vals.data(), vals.size() * 8, c->w->stream);
+    op_encode(c, dv.w(), 1, 2 * PASTA_T, PASTA_T, (int)half, pl.w());
+    op_lift_ntt(c, pl.w(), 1, mask.w());
     if (rt_sync(c->w->stream)) return dev_fail("feistel mask");
-    rt_free(dv); rt_free(pl);
+    c->d_feistel_mask = mask.release();
     return HHE_OK;
 }
 
+// Public tables of one block counter, built on the device on first use.  Footprint per counter: (4 x 128 x L + 4) x N
+// words for `pdiag` (fused pipeline) or `diag` (op-by-op schedule, HHE_MATMUL=0) -- 384 MiB at N = 2^15, L = 3; the
+// babystep-giantstep variant adds the same again on its first use.  hhe_pasta3_clear_block_cache() releases them.
 int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
 {
     auto it = c->blocks.find(block);
@@ -222,36 +223,35 @@ int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
     const size_t ndiag = (size_t)(PASTA_R + 1) * PASTA_T;
     std::vector<u64> mats((size_t)(PASTA_R + 1) * 2 * PASTA_T * PASTA_T), rcs((size_t)(PASTA_R + 1) * 2 * PASTA_T);
     pasta3_block_randomness(c->t, PASTA_NONCE, block, mats.data(), rcs.data());
-    BlockTables bt;
-    u64 *d_mats = (u64 *)rt_malloc(mats.size() * 8), *d_rcs = (u64 *)rt_malloc(rcs.size() * 8);
-    u64 *slots = (u64 *)rt_malloc(ndiag * n * 8);
-    bt.diag = (u64 *)rt_malloc(ndiag * L * n * 8);
-    bt.rc = (u64 *)rt_malloc((size_t)(PASTA_R + 1) * n * 8);
-    if (!d_mats || !d_rcs || !slots || !bt.diag || !bt.rc) return dev_fail("block table alloc");
-    rt_h2d(d_mats, mats.data(), mats.size() * 8, c->w->stream);
-    rt_h2d(d_rcs, rcs.data(), rcs.size() * 8, c->w->stream);
+    const bool fused = c->matmul_mode == 1;
+    DevBuf d_mats(mats.size() * 8), d_rcs(rcs.size() * 8), slots(ndiag * n * 8), diag(ndiag * L * n * 8),
+        rc((size_t)(PASTA_R + 1) * n * 8), pdiag(fused ? ndiag * L * n * 8 : 8);
+    if (!d_mats.p || !d_rcs.p || !slots.p || !diag.p || !rc.p || !pdiag.p) return dev_fail("block table alloc");
+    rt_h2d(d_mats.p, mats.data(), mats.size() * 8, c->w->stream);
+    rt_h2d(d_rcs.p, rcs.data(), rcs.size() * 8, c->w->stream);
     // 128 diagonals per affine layer -> slot image -> INTT mod t (= batch encode) -> lift + NTT per limb
-    rt_memset(slots, 0, ndiag * n * 8, c->w->stream);
+    rt_memset(slots.p, 0, ndiag * n * 8, c->w->stream);
     DiagArgs d;
     memset(&d, 0, sizeof(d));
-    d.mats = d_mats; d.out = slots; d.slot_map = c->d_slot_map; d.logn = c->logn;
+    d.mats = d_mats.w(); d.out = slots.w(); d.slot_map = c->d_slot_map; d.logn = c->logn;
     k_diag(d, c->w->stream);
-    op_ntt(c, slots, ndiag, c->mod_t, 1, true);
-    op_lift_ntt(c, slots, ndiag, bt.diag);
+    op_ntt(c, slots.w(), ndiag, c->mod_t, 1, true);
+    op_lift_ntt(c, slots.w(), ndiag, diag.w());
     // round constants: rc1 -> slots [0,128), rc2 -> slots [N/2, N/2+128) (pasta_3_plain.cpp:286-295)
-    op_encode(c, d_rcs, PASTA_R + 1, 2 * PASTA_T, PASTA_T, (int)half, bt.rc);
-    if (c->matmul_mode == 1) {
+    op_encode(c, d_rcs.w(), PASTA_R + 1, 2 * PASTA_T, PASTA_T, (int)half, rc.w());
+    if (fused) {
         // pdiag = diag o pi_g for g = elt(rotate_rows -1): multiplier tables in the rotated NTT frame
-        bt.pdiag = (u64 *)rt_malloc(ndiag * L * n * 8);
-        if (!bt.pdiag) return dev_fail("block table alloc");
         PermArgs p;
         memset(&p, 0, sizeof(p));
-        p.in = bt.diag; p.out = bt.pdiag; p.mods = c->d_mods; p.logn = c->logn; p.count = (int)(ndiag * L); p.L = L;
+        p.in = diag.w(); p.out = pdiag.w(); p.mods = c->d_mods; p.logn = c->logn; p.count = (int)(ndiag * L); p.L = L;
         p.out_item_stride = (size_t)L * n; p.elt = galois_elt_from_step(c, -1);
         k_perm(p, c->w->stream);
     }
     if (rt_sync(c->w->stream)) return dev_fail("block tables");
-    rt_free(d_mats); rt_free(d_rcs); rt_free(slots);
+    BlockTables bt;
+    bt.rc = rc.release();
+    if (fused) bt.pdiag = pdiag.release();  // the fused pipeline reads only pdiag: diag is dropped with this scope
+    else bt.diag = diag.release();
     auto ins = c->blocks.emplace(block, bt);
     *out = &ins.first->second;
     return HHE_OK;
@@ -266,19 +266,18 @@ int ensure_bsgs_tables(hhe_ctx *c, u64 block, BlockTables *bt)
     const size_t ndiag = (size_t)(PASTA_R + 1) * PASTA_T;
     std::vector<u64> mats((size_t)(PASTA_R + 1) * 2 * PASTA_T * PASTA_T), rcs((size_t)(PASTA_R + 1) * 2 * PASTA_T);
     pasta3_block_randomness(c->t, PASTA_NONCE, block, mats.data(), rcs.data());
-    u64 *d_mats = (u64 *)rt_malloc(mats.size() * 8), *slots = (u64 *)rt_malloc(ndiag * n * 8);
-    bt->bsgs = (u64 *)rt_malloc(ndiag * L * n * 8);
-    if (!d_mats || !slots || !bt->bsgs) return dev_fail("bsgs table alloc");
-    rt_h2d(d_mats, mats.data(), mats.size() * 8, c->w->stream);
-    rt_memset(slots, 0, ndiag * n * 8, c->w->stream);
+    DevBuf d_mats(mats.size() * 8), slots(ndiag * n * 8), bsgs(ndiag * L * n * 8);
+    if (!d_mats.p || !slots.p || !bsgs.p) return dev_fail("bsgs table alloc");
+    rt_h2d(d_mats.p, mats.data(), mats.size() * 8, c->w->stream);
+    rt_memset(slots.p, 0, ndiag * n * 8, c->w->stream);
     BsgsDiagArgs d;
     memset(&d, 0, sizeof(d));
-    d.mats = d_mats; d.out = slots; d.slot_map = c->d_slot_map; d.logn = c->logn; d.n1 = 16;
+    d.mats = d_mats.w(); d.out = slots.w(); d.slot_map = c->d_slot_map; d.logn = c->logn; d.n1 = 16;
     k_bsgs_diag(d, c->w->stream);
-    op_ntt(c, slots, ndiag, c->mod_t, 1, true);
-    op_lift_ntt(c, slots, ndiag, bt->bsgs);
+    op_ntt(c, slots.w(), ndiag, c->mod_t, 1, true);
+    op_lift_ntt(c, slots.w(), ndiag, bsgs.w());
     if (rt_sync(c->w->stream)) return dev_fail("bsgs tables");
-    rt_free(d_mats); rt_free(slots);
+    bt->bsgs = bsgs.release();
     return HHE_OK;
 }
 
@@ -384,11 +383,6 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     u64 *accp0 = c->w->ws_ct[1], *accp1 = c->w->ws_ct[1] + bln;
     u64 *c0n[2] = {c->w->ws_ct[2], c->w->ws_ct[2] + bln};
     u64 *scr = c->w->ws_ct[3], *r = c->w->ws_ct[3] + bln, *scr2 = c->w->ws_ct3;
-    // the c0 branch of step i (K5) is only needed by the c0 branch of step i+1: run it on the lane's side stream,
-    // beside the latency-bound c1 chain (K4b of this step, digit transforms of the next)
-    Lane &lane = *c->w;
-    const bool side = c->side_stream && lane.side != nullptr;
-    rt_stream s5 = side ? lane.side : lane.stream;
     rt_memset(c->w->ws_ct[1], 0, 2 * bln * 8, c->w->stream);
     {   // c0 -> NTT form ; d = galois(c1)
         NttArgs a = ntt_args(c, state, c0n[0], B * L, 0, L);
@@ -404,33 +398,23 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     // The c0 branch of step i (96 polynomials per 32 items: it cannot fill the 1024 workgroup slots on its own) only feeds
     // the c0 branch of step i+1, and like the digit transforms of step i+1 it depends on nothing later than the inverse
     // transforms of step i: both go into one grid (k_ntt2_fwd).
-    const bool merge = c->merge_fwd && !side && !c->mac_fuse && !(c->digit_sub && c->digit_sub < B);
+    const bool merge = c->merge_fwd != 0;
     NttArgs k5;
     bool k5_pending = false;
     for (int i = 0; i < PASTA_T - 1; ++i) {
         const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
         {   // digits T[I][J] = NTT_J(d[I] mod q_J) and S_k[J] = sum_I T[I][J] * key[I][k][J]; the I = J digit also feeds
-            // the plain product (HHE_MACFUSE=1: the row pass keeps S in registers and never writes T).
-            const size_t sub = (c->digit_sub && c->digit_sub < B) ? c->digit_sub : B;
-            for (size_t o = 0; o < B; o += sub) {
-                const size_t bs = std::min(sub, B - o);
-                NttArgs a = ntt_args(c, c->w->ws_d + o * ln, c->w->ws_T, bs * L * K, 0, K);
-                a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
-                a.store_op = STORE_LAZY;
-                KsMacArgs m;
-                memset(&m, 0, sizeof(m));
-                m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S + o * 2 * K * n; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)bs; m.L = L; m.K = K;
-                m.acc = accp1 + o * ln; m.mul_ptrs = d_pdiag_ptrs + o; m.mul_shift = shift;
-                if (side && i > 0 && o == 0) rt_stream_wait_event(lane.stream, lane.ev_k5[(i - 1) & 1]);  // S and r are about to be overwritten
-                if (c->mac_fuse) {
-                    k_ntt_first_pass(a, false, c->w->stream);
-                    k_digit_mac(a, m, c->w->stream);
-                } else {
-                    if (k5_pending) { k_ntt2_fwd(k5, a, c->w->stream); k5_pending = false; }  // c0 branch of the previous step first: its long epilogue overlaps the digit tiles
-                    else k_ntt(a, false, c->w->stream);
-                    k_ks_mac(m, c->w->stream);
-                }
-            }
+            // the plain product
+            NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
+            a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+            a.store_op = STORE_LAZY;
+            KsMacArgs m;
+            memset(&m, 0, sizeof(m));
+            m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
+            m.acc = accp1; m.mul_ptrs = d_pdiag_ptrs; m.mul_shift = shift;
+            if (k5_pending) { k_ntt2_fwd(k5, a, c->w->stream); k5_pending = false; }  // c0 branch of the previous step first: its long epilogue overlaps the digit tiles
+            else k_ntt(a, false, c->w->stream);
+            k_ks_mac(m, c->w->stream);
         }
         {   // r_k = INTT(S_k[special]) + floor(q_sp/2), then c1 of the next state in coefficient form, already passed
             // through the Galois map for the next digits (its mod-down epilogue reads r_1)
@@ -438,28 +422,21 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             a.src_item_polys = 1; a.src_item_stride = (size_t)K * n; a.store_op = STORE_RSP;
             NttArgs a1 = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
             a1.src_item_polys = L; a1.src_item_stride = (size_t)2 * K * n; a1.store_op = STORE_KS1;
-            a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = (c->probe & 2) ? 0 : g;  // probe bit 1: no Galois scatter (results invalid)
+            a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = g;
             if (merge) k_ntt2_inv(a, a1, c->w->stream);
-            else {
-                k_ntt(a, true, c->w->stream);
-                if (side) { rt_event_record(lane.ev_k4a[i & 1], lane.stream); rt_stream_wait_event(s5, lane.ev_k4a[i & 1]); }
-                k_ntt(a1, true, c->w->stream);
-            }
+            else { k_ntt(a, true, c->w->stream); k_ntt(a1, true, c->w->stream); }
         }
         {   // c0 of the next state in NTT form + permuted-frame product of the current c0
             NttArgs a = ntt_args(c, r, scr2, B * L, 0, L);
             a.src_item_polys = L; a.src_item_stride = 2 * n; a.src_div = L; a.load_op = LOAD_RNEG;
             a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.aux_r = c->w->ws_S; a.acc = accp0;
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g;
-            if (c->probe & 1) a.store_op = STORE_PLAIN;  // timing probe: price of the fused c0 epilogue (results invalid)
             if (merge) { k5 = a; k5_pending = true; }  // launched in the grid of the next step's digit transforms
-            else k_ntt(a, false, s5);
-            if (side) rt_event_record(lane.ev_k5[i & 1], s5);
+            else k_ntt(a, false, c->w->stream);
         }
         cur ^= 1;
     }
     if (k5_pending) k_ntt(k5, false, c->w->stream);
-    if (side) rt_stream_wait_event(lane.stream, lane.ev_k5[(PASTA_T - 2) & 1]);
     const size_t shift = ((size_t)layer * PASTA_T + (PASTA_T - 1)) * ln;
     {   // last state: products only (a "virtual" rotation keeps the frame uniform)
         NttArgs a = ntt_args(c, c->w->ws_d, scr, B * L, 0, L);
@@ -487,15 +464,6 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
 extern "C" int hhe_ntt(hhe_ctx *c, uint64_t *polys, size_t count, int mod_base, int mod_cycle, int inverse)
 {
     if (!c || !polys || mod_cycle < 1 || mod_base < 0 || mod_base + mod_cycle > c->nmod) return fail(HHE_ERR_INVALID, "hhe_ntt: bad arguments");
-    if (const char *probe = getenv("HHE_NTT_PROBE")) {  // timing probes for tools/ntt_micro.py (results are garbage)
-        NttArgs a = ntt_args(c, polys, polys, count, mod_base, mod_cycle);
-        const int p = atoi(probe);
-        if (p & 1) a.load_op = 99;
-        if (p & 2) a.store_op = 99;
-        a.probe = p;
-        k_ntt(a, inverse != 0, c->w->stream);
-        return HHE_OK;
-    }
     op_ntt(c, polys, count, mod_base, mod_cycle, inverse != 0);
     return HHE_OK;
 }
@@ -581,27 +549,6 @@ extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, si
     return op_relinearize(c, a3, out, B);
 }
 
-// the fused matmul loop is launch bound on the host (1143 launches per affine layer): on the internal streams it is
-// captured once per (layer, batch) into a hipGraph and replayed; table pointers live in lane-owned device memory
-// whose contents, not address, change between calls
-static int run_matmul_fused(hhe_ctx *c, int layer, const u64 *const *d_diag, size_t B)
-{
-    Lane &ln = *c->w;
-    if (!c->use_graphs || !ln.own_stream || d_diag != ln.d_ptrs) return matmul_diagonal_fused(c, layer, d_diag, B);
-    const auto key = std::make_pair(layer, B);
-    auto it = ln.graphs.find(key);
-    if (it == ln.graphs.end()) {
-        if (rt_capture_begin(ln.stream)) return matmul_diagonal_fused(c, layer, d_diag, B);
-        int rc = matmul_diagonal_fused(c, layer, d_diag, B);
-        void *exec = rt_capture_end(ln.stream);
-        if (rc) { rt_graph_destroy(exec); return rc; }
-        if (!exec) { c->use_graphs = 0; return matmul_diagonal_fused(c, layer, d_diag, B); }
-        it = ln.graphs.emplace(key, exec).first;
-    }
-    if (rt_graph_launch(it->second, ln.stream)) return dev_fail("hipGraphLaunch");
-    return HHE_OK;
-}
-
 // one chunk of the batch on the current lane (c->w): the schedule of PASTA_SEAL::decomposition (pasta_3_seal.cpp:123-170)
 static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d_diag, const u64 *const *d_rc,
                              const u64 *cw_padded_host, u64 *out, size_t B, bool bsgs)
@@ -615,7 +562,7 @@ static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d
     // state <- enc_ssk[0] for every item (pasta_3_seal.cpp:126)
     op_elt(c, ELT_BCAST, nullptr, enc_key, state, B * 2 * L, 0, L, 2 * L);
     for (int r = 0; r <= PASTA_R && !rc; ++r) {
-        if ((rc = bsgs ? matmul_bsgs(c, r, d_diag, B) : fused ? run_matmul_fused(c, r, d_diag, B) : matmul_diagonal(c, r, d_diag, B))) break;
+        if ((rc = bsgs ? matmul_bsgs(c, r, d_diag, B) : fused ? matmul_diagonal_fused(c, r, d_diag, B) : matmul_diagonal(c, r, d_diag, B))) break;
         // add_rc (:205-211)
         op_add_plain(c, state, nullptr, d_rc, (size_t)r * n, false, false, false, state, B);
         // mix (:417-423)

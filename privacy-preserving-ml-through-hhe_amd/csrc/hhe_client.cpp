@@ -17,12 +17,6 @@ void barrett_ratio(u64 q, u64 &lo, u64 &hi)
     hi = (u64)(two64 / q);
     lo = (u64)(((two64 % q) << 64) / q);
 }
-struct DevBuf {  // scoped device allocation
-    void *p = nullptr;
-    explicit DevBuf(size_t bytes) { p = rt_malloc(bytes ? bytes : 8); }
-    ~DevBuf() { if (p) rt_free(p); }
-    u64 *w() const { return (u64 *)p; }
-};
 
 int keystream_into(hhe_ctx *c, const uint64_t *key, uint64_t first_block, size_t nblocks, u64 *ks, rt_stream st)
 {

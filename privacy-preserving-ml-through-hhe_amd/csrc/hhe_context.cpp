@@ -310,27 +310,17 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     c->ksc.half = kf.half;
     for (int j = 0; j < L; ++j) { c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j]; }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
-    if (const char *e = getenv("HHE_GRAPH")) c->use_graphs = atoi(e);
-    if (const char *e = getenv("HHE_MACFUSE")) c->mac_fuse = atoi(e);
     if (const char *e = getenv("HHE_LAZY8")) c->lazy8 = atoi(e);
     if (const char *e = getenv("HHE_MERGE")) c->merge_fwd = atoi(e);
-    if (const char *e = getenv("HHE_SIDE")) c->side_stream = atoi(e);
-    if (const char *e = getenv("HHE_PIPE_PROBE")) c->probe = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
     if (const char *e = getenv("HHE_FC_SHARED")) c->fc_shared = atoi(e);
     if (const char *e = getenv("HHE_FC_CHUNK")) c->fc_chunk = (size_t)std::max(0, atoi(e));
-    if (const char *e = getenv("HHE_DIGIT_SUB")) c->digit_sub = (size_t)std::max(0, atoi(e));
     if (const char *e = getenv("HHE_STREAMS")) c->nstreams = std::max(0, std::min(HHE_MAX_STREAMS, atoi(e)));
-    // eager launching (default) amortises its per-launch dispatch gaps over bigger chunks: measured 211 /s at 32, 221 at 64,
-    // 225 at 128 items; with graph replay 32 is best (227; the digit transforms of a chunk then stay in the Infinity Cache)
-    c->chunk = c->use_graphs ? 32 : 128;
     if (const char *e = getenv("HHE_CHUNK")) c->chunk = (size_t)std::max(1, atoi(e));
     for (int s = 1; s <= c->nstreams; ++s) {
         c->lanes[s].stream = rt_stream_create();
         c->lanes[s].own_stream = true;
         c->lanes[s].ev_done = rt_event_create();
-        c->lanes[s].side = rt_stream_create();
-        for (int e = 0; e < 2; ++e) { c->lanes[s].ev_k4a[e] = rt_event_create(); c->lanes[s].ev_k5[e] = rt_event_create(); }
     }
     c->ev_fork = rt_event_create();
     {   // a digit d_I < q_I may enter NTT_J unreduced when q_I < 4 q_J (butterfly inputs live in [0,4q))
@@ -351,8 +341,6 @@ static void free_lane(Lane &ln)
     for (auto &p : ln.ws_ct) { rt_free(p); p = nullptr; }
     rt_free(ln.ws_rot); ln.ws_rot = nullptr; ln.rot_cap = 0;
     rt_free(ln.ws_tp); ln.ws_tp = nullptr; ln.tp_cap = ln.tp_depth = 0;
-    for (auto &kv : ln.graphs) rt_graph_destroy(kv.second);
-    ln.graphs.clear();
     rt_free((void *)ln.d_ptrs); ln.d_ptrs = nullptr; ln.ptr_cap = 0;
     rt_free(ln.bz_aq); rt_free(ln.bz_bq); rt_free(ln.bz_ab); rt_free(ln.bz_bb); rt_free(ln.bz_dq); rt_free(ln.bz_db);
     ln.ws_T = ln.ws_S = ln.ws_d = ln.ws_ct3 = ln.ws_plain = ln.ws_vals = nullptr;
@@ -363,7 +351,6 @@ static void sync_all(hhe_ctx *c)
 {
     for (auto &ln : c->lanes) {
         if (&ln == &c->lanes[0] || ln.own_stream) rt_sync(ln.stream);
-        if (ln.side) rt_sync(ln.side);
     }
 }
 
@@ -412,8 +399,7 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
     for (auto &ln : c->lanes) {
         free_lane(ln);
         rt_event_destroy(ln.ev_done);
-        if (ln.own_stream) { rt_stream_destroy(ln.stream); rt_stream_destroy(ln.side); }
-        for (int e = 0; e < 2; ++e) { rt_event_destroy(ln.ev_k4a[e]); rt_event_destroy(ln.ev_k5[e]); }
+        if (ln.own_stream) rt_stream_destroy(ln.stream);
     }
     rt_event_destroy(c->ev_fork);
     for (auto &p : c->d_rk_slot) rt_free(p);

@@ -18,8 +18,6 @@ constexpr int HHE_RELIN_SLOTS = 4;
 struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `cap` ciphertexts)
     rt_stream stream = nullptr;
     void *ev_done = nullptr;
-    rt_stream side = nullptr;      // second stream of the lane: the c0 branch of a rotation step runs beside the c1 branch
-    void *ev_k4a[2] = {nullptr, nullptr}, *ev_k5[2] = {nullptr, nullptr};
     bool own_stream = false;
     size_t cap = 0;
     u64 *ws_T = nullptr;     // [B][L][K][N]
@@ -33,9 +31,8 @@ struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `c
     u64 *bz_ab = nullptr, *bz_bb = nullptr;  // [B][2][L+1][N]
     u64 *bz_dq = nullptr;    // [B][3][L][N]
     u64 *bz_db = nullptr;    // [B][3][L+1][N]
-    const u64 **d_ptrs = nullptr;  // [2*cap] per-item public-table pointers (diag | rc), fixed address for graph replay
+    const u64 **d_ptrs = nullptr;  // [2*cap] per-item public-table pointers (diag | rc)
     size_t ptr_cap = 0;
-    std::map<std::pair<int, size_t>, void *> graphs;  // (affine layer, batch) -> captured fused-matmul graph
     u64 *ws_rot = nullptr;   // [B][16][2][L][N] babystep rotations (allocated on first BSGS use)
     size_t rot_cap = 0;
     u64 *ws_tp = nullptr;    // FC shared digits: [depth][B][L][K][N] digit transforms of the un-rotated c1 of each trie level
@@ -54,16 +51,10 @@ struct hhe_ctx {
     int nmod = 0;                  // K + (L+1) + 1
     int mod_t = 0;                 // index of the plain modulus
     int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
-    int use_graphs = 0;            // HHE_GRAPH=1: replay the fused matmul loop as a hipGraph on the internal streams (+6 %).  Opt-in:
-                                   // on ROCm 7.2 replays go wrong after ~200 eager launches on other streams (hhe_kernels.hip)
-    int side_stream = 0;           // overlap the off-critical-path c0 update (K5) with the next digit transforms
-    int probe = 0;                 // HHE_PIPE_PROBE timing probes (bench only; results invalid when set)
     u64 fc_fallbacks = 0;          // how often the shared-digit path had to be recomputed exactly
     int fc_shared = 1;             // FC rotation trie: children of a node share the digit transforms of its c1 (HHE_FC_SHARED; 2 = force the fallback, tests)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
     size_t fc_chunk = 80;          // items per internal chunk of hhe_fc_row (0 = whole batch); measured 40: 67.1, 80: 64.9, 160: 64.0 ms per MNIST sample
-    size_t digit_sub = 0;          // >0: run the digit transforms + inner product in sub-batches of this many items (T stays cache resident)
-    int mac_fuse = 0;              // fused digit-NTT row pass + key-switch inner product in the matmul loop
     int merge_fwd = 1;             // fused matmul: the c0 branch of a step shares the grid of the next step's digit transforms (HHE_MERGE)
     int lazy8 = 1;                 // forward NTT rounds with one range fold per register round where the moduli allow it (HHE_LAZY8)
     int matmul_mode = 1;           // 1: fused 20-transform pipeline (default), 0: op-by-op schedule
@@ -95,7 +86,7 @@ struct hhe_ctx {
     Lane lanes[1 + HHE_MAX_STREAMS];
     Lane *w = &lanes[0];
     int nstreams = 2;      // internal streams used by hhe_pasta3_transcipher (0 = caller's stream only)
-    size_t chunk = 128;    // items per chunk (HHE_CHUNK): 128 for eager launching, 32 with graph replay (set in hhe_ctx_create)
+    size_t chunk = 128;    // items per chunk (HHE_CHUNK); measured 211 /s at 32, 221 at 64, 225 at 128 items (round 1)
     void *ev_fork = nullptr;
 
     size_t ct_words() const { return (size_t)2 * L * n; }
@@ -126,6 +117,16 @@ inline int ntt_lazy8(const hhe_ctx *c, int mod_base, int mod_cycle)
     }
     return 1;
 }
+
+struct DevBuf {  // scoped device allocation (freed on every exit path unless released)
+    void *p = nullptr;
+    explicit DevBuf(size_t bytes) { p = rt_malloc(bytes ? bytes : 8); }
+    ~DevBuf() { if (p) rt_free(p); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    u64 *w() const { return (u64 *)p; }
+    u64 *release() { u64 *r = (u64 *)p; p = nullptr; return r; }
+};
 
 void hhe_set_error(const std::string &msg);
 int lane_reserve(hhe_ctx *c, Lane &ln, size_t B);

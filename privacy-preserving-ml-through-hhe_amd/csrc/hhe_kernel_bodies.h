@@ -13,21 +13,15 @@
 #include "hhe_modarith.h"
 
 constexpr int NTT_THREADS = 256;
-// Two tile geometries share the bodies below:
-//   V = 0: 4096-point tiles, radix-16/8 register rounds (16 points per lane) -- the stand-alone NTT passes
-//   V = 1: 2048-point tiles, radix-8/4 rounds (8 points per lane, half the registers) -- the fused digit-NTT +
-//          key-switch inner product kernel, which also keeps 16 accumulators per lane
-template <int V> struct NttTile { static constexpr int LOG = V == 0 ? 12 : 11; };
-template <int V, int LOGM> struct NttSchedV;  // register-radix schedule per sub-transform size
-template <> struct NttSchedV<0, 5> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
-template <> struct NttSchedV<0, 6> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
-template <> struct NttSchedV<0, 7> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 4 : 3; } };
-template <> struct NttSchedV<0, 8> { static constexpr int R = 2; static constexpr int rho(int i) { return 4; } };
-template <> struct NttSchedV<1, 5> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
-template <> struct NttSchedV<1, 6> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
-template <> struct NttSchedV<1, 7> { static constexpr int R = 3; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
-template <> struct NttSchedV<1, 8> { static constexpr int R = 3; static constexpr int rho(int i) { return i == 2 ? 2 : 3; } };
-template <int V> struct NttLds { static constexpr int ELEMS = (1 << NttTile<V>::LOG) + 512; };  // rows of pitch C+1
+// 4096-point tiles, radix-16/8 register rounds (16 points per lane).  (A 2048-point / radix-8 geometry at 5-8 waves per SIMD
+// was measured in round 1: butterflies-only 0.31 vs 0.28 us per transform, and removed.)
+struct NttTile { static constexpr int LOG = 12; };
+template <int LOGM> struct NttSched;  // register-radix schedule per sub-transform size
+template <> struct NttSched<5> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
+template <> struct NttSched<6> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
+template <> struct NttSched<7> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 4 : 3; } };
+template <> struct NttSched<8> { static constexpr int R = 2; static constexpr int rho(int i) { return 4; } };
+struct NttLds { static constexpr int ELEMS = (1 << NttTile::LOG) + 512; };  // rows of pitch C+1
 
 HD u32 bitrev_n(u32 v, int bits)
 {
@@ -158,8 +152,7 @@ HD void ntt_load_full(const NttArgs &a, const NttGeom &g, const ModDev &m, const
     for (int k = 0; k < NP; k++) {
         int x, lane, gi;
         ntt_pair<STRIDED>(a, g, tid + k * NTT_THREADS, x, lane, gi, l0[k], l1[k]);
-        if (FIRST && a.load_op == 99) { v[k].a = (u64)(x * 131 + lane); v[k].b = v[k].a + 1; }  // timing probe (no global read)
-        else v[k] = ld2_stream(src + gi);
+        v[k] = ld2_stream(src + gi);
     }
 #pragma unroll
     for (int k = 0; k < NP; k++) {
@@ -186,10 +179,7 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
     for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) {
         int x, lane, gi, l0, l1;
         ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
-        U2 v;
-        if (FIRST && a.load_op == 99) { v.a = (u64)(x * 131 + lane); v.b = v.a + 1; }  // timing probe (no global read)
-        else v = ld2(src + gi);
-        v = ntt_load_op<FIRST>(a, m, g.poly, v);
+        const U2 v = ntt_load_op<FIRST>(a, m, g.poly, ld2(src + gi));
         lds[l0] = v.a;
         lds[l1] = v.b;
     }
@@ -328,7 +318,6 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
     constexpr bool LAST = (STRIDED == INVERSE);
     const u64 q = m.q, q2 = q << 1;
     u64 v[2] = {lds[l0], lds[l1]};
-    if (a.store_op == 99) { if (v[0] == 0x123456789abcdefULL) dst[gi] = v[0]; return; }  // timing probe (no global write)
     if (!LAST || (!INVERSE && a.store_op == STORE_LAZY)) { st2_stream(dst + gi, U2{v[0], v[1]}); return; }
     if (INVERSE) {
         const bool st = a.store_op == STORE_SCALE_T;
@@ -635,61 +624,6 @@ HD void ks_corr_body(const KsCorrArgs &a, size_t gid)
     for (int I = 0; I < a.L; I++)
         if (I != J) sum = addmod(sum, mulmod(a.key[(((size_t)I * 2 + k) * a.K + J) * n + x], a.qmod[I * a.K + J], m), m.q);
     a.corr[gid] = mulmod(sum, a.shat[(size_t)J * n + x], m);
-}
-
-// Fused digit NTT + key-switch inner product (row pass of NTT_J(d_I mod q_J), V = 1 tiles): after the last
-// round the tile of T[b][I][J] sits in LDS; multiply it with key[I][0..1][J] straight into per-lane accumulators
-// instead of writing T and re-reading it in ks_mac_kernel.  acc[k][0..1]: pair k, element 0/1; *_0 for key poly 0.
-constexpr int DMAC_NPAIR = (1 << NttTile<1>::LOG) / 2 / NTT_THREADS;
-HD void digit_mac_phase(const NttArgs &a, const KsMacArgs &mk, int bx, int by, int I, int tid, const u64 *lds, u64 *acc0, u64 *acc1)
-{
-    const NttGeom g = ntt_geom(a, bx, by);
-    const int J = g.poly % a.K;
-    const size_t b = g.poly / ((size_t)a.K * a.L);
-    const ModDev &m = a.mods[J];
-    const u64 q = m.q, q2 = q << 1;
-    const int E2 = (g.M * g.C) >> 1;
-    const u64 *k0 = mk.key + (((size_t)I * 2 + 0) * a.K + J) * g.n;
-    const u64 *k1 = mk.key + (((size_t)I * 2 + 1) * a.K + J) * g.n;
-    for (int k = 0; k < DMAC_NPAIR; k++) {
-        const int e2 = tid + k * NTT_THREADS;
-        if (e2 >= E2) break;
-        int x, lane, gi, l0, l1;
-        ntt_pair<false>(a, g, e2, x, lane, gi, l0, l1);
-        u64 v[2] = {lds[l0], lds[l1]};
-        for (int e = 0; e < 2; e++) {
-            v[e] -= (v[e] >= q2) ? q2 : 0;
-            v[e] -= (v[e] >= q) ? q : 0;
-        }
-        const U2 c0 = ld2(k0 + gi), c1 = ld2(k1 + gi);
-        acc0[2 * k] = addmod(acc0[2 * k], mulmod(v[0], c0.a, m), q);
-        acc0[2 * k + 1] = addmod(acc0[2 * k + 1], mulmod(v[1], c0.b, m), q);
-        acc1[2 * k] = addmod(acc1[2 * k], mulmod(v[0], c1.a, m), q);
-        acc1[2 * k + 1] = addmod(acc1[2 * k + 1], mulmod(v[1], c1.b, m), q);
-        if (mk.acc && I == J) {  // diagonal digit = NTT_J(galois(c1)): the plain product of the fused matmul
-            const U2 d = ld2(mk.mul_ptrs[b] + mk.mul_shift + (size_t)J * g.n + gi);
-            u64 *ap = mk.acc + (b * a.L + J) * g.n + gi;
-            U2 ac = ld2(ap);
-            ac.a = addmod(ac.a, mulmod(v[0], d.a, m), q);
-            ac.b = addmod(ac.b, mulmod(v[1], d.b, m), q);
-            st2(ap, ac);
-        }
-    }
-}
-HD void digit_mac_store(const NttArgs &a, const KsMacArgs &mk, int bx, int by, int tid, const u64 *acc0, const u64 *acc1)
-{
-    const NttGeom g = ntt_geom(a, bx, by);  // by = any digit poly of this (b, J)
-    const int J = g.poly % a.K;
-    const size_t b = g.poly / ((size_t)a.K * a.L);
-    const int E2 = (g.M * g.C) >> 1;
-    for (int k = 0; k < DMAC_NPAIR; k++) {
-        const int e2 = tid + k * NTT_THREADS;
-        if (e2 >= E2) break;
-        int x, lane, gi, l0, l1;
-        ntt_pair<false>(a, g, e2, x, lane, gi, l0, l1);
-        st2(mk.S + ((b * 2 + 0) * a.K + J) * g.n + gi, U2{acc0[2 * k], acc0[2 * k + 1]});
-        st2(mk.S + ((b * 2 + 1) * a.K + J) * g.n + gi, U2{acc1[2 * k], acc1[2 * k + 1]});
-    }
 }
 
 // closes the leaf sums of the FC rotation trie: gid over [B][2][L][N]

@@ -52,56 +52,21 @@ void *rt_event_create()
 void rt_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 int rt_event_record(void *ev, rt_stream s) { return rt_check(hipEventRecord((hipEvent_t)ev, (hipStream_t)s), "hipEventRecord"); }
 int rt_stream_wait_event(rt_stream s, void *ev) { return rt_check(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0), "hipStreamWaitEvent"); }
-int rt_capture_begin(rt_stream s)
-{
-    if (!s) return -1;  // the legacy default stream cannot be captured
-    return rt_check(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-}
-// The executable graph is kept together with the captured template (cheap, and independent of how much of the template the
-// runtime still references).  NOTE (ROCm 7.2 on gfx950, measured): after roughly 200-250 eager kernel launches on OTHER
-// streams of the process, replays of an instantiated graph compute wrong results (deterministically; a graph captured
-// afterwards is right again; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 avoids it at the price of the whole benefit).  Graph replay is
-// therefore opt-in (HHE_GRAPH=1) for processes that only transcipher; see DESIGN.md.
-struct RtGraph {
-    hipGraph_t graph;
-    hipGraphExec_t exec;
-};
-void *rt_capture_end(rt_stream s)
-{
-    hipGraph_t g = nullptr;
-    if (rt_check(hipStreamEndCapture((hipStream_t)s, &g), "hipStreamEndCapture") || !g) return nullptr;
-    hipGraphExec_t e = nullptr;
-    if (rt_check(hipGraphInstantiate(&e, g, nullptr, nullptr, 0), "hipGraphInstantiate") || !e) {
-        (void)hipGraphDestroy(g);
-        return nullptr;
-    }
-    return (void *)new RtGraph{g, e};
-}
-int rt_graph_launch(void *exec, rt_stream s) { return rt_check(hipGraphLaunch(((RtGraph *)exec)->exec, (hipStream_t)s), "hipGraphLaunch"); }
-void rt_graph_destroy(void *exec)
-{
-    if (!exec) return;
-    RtGraph *r = (RtGraph *)exec;
-    (void)hipGraphExecDestroy(r->exec);
-    (void)hipGraphDestroy(r->graph);
-    delete r;
-}
-
 // ---------------------------------------------------------------- NTT
 // one-dimensional grids (gridDim.y is limited to 65535 polynomials): block -> (tile, poly), tiles per poly = 2^tiles_log
 #define NTT_BX(a) ((int)(blockIdx.x & ((1u << (a).tiles_log) - 1)))
 #define NTT_BY(a) ((int)(blockIdx.x >> (a).tiles_log))
 
 // CC = tile columns as a compile-time constant (full tiles) or -1 (ragged tiles of small N: taken from the arguments)
-template <int V, int LOGM, bool STRIDED, bool INVERSE, int CC>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC>
 struct NttRounds {
-    static constexpr int R = NttSchedV<V, LOGM>::R;
+    static constexpr int R = NttSched<LOGM>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
     template <int I, int S0, bool LAZY8 = false>
     static __device__ __forceinline__ void fwd(const NttArgs &a, int bx, int by, u64 *lds)
     {
         if constexpr (I < R) {
-            constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
+            constexpr int RHO = NttSched<LOGM>::rho(I);
             ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC>(a, bx, by, threadIdx.x, lds);
             __syncthreads();
             fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
@@ -111,41 +76,43 @@ struct NttRounds {
     static __device__ __forceinline__ void inv(const NttArgs &a, int bx, int by, u64 *lds)
     {
         if constexpr (I >= 0) {
-            constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
+            constexpr int RHO = NttSched<LOGM>::rho(I);
             ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC>(a, bx, by, threadIdx.x, lds);
             __syncthreads();
             inv<I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
         }
     }
 };
+// the register rounds of one pass over the tile staged in LDS (each round ends with a barrier)
+template <int LOGM, bool STRIDED, bool INVERSE, int CC>
+static __device__ __forceinline__ void ntt_tile_rounds(const NttArgs &a, int bx, int by, u64 *lds)
+{
+    if constexpr (!INVERSE) {
+        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, true>(a, bx, by, lds);
+        else NttRounds<LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, false>(a, bx, by, lds);
+    } else {
+        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC>::template inv<NttSched<LOGM>::R - 1, LOGM, true>(a, bx, by, lds);
+        else NttRounds<LOGM, STRIDED, INVERSE, CC>::template inv<NttSched<LOGM>::R - 1, LOGM, false>(a, bx, by, lds);
+    }
+}
 
 // one pass of one tile: load phase, register rounds through LDS, store phase
-template <int V, int LOGM, bool STRIDED, bool INVERSE, bool FULL>
+template <int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 static __device__ __forceinline__ void ntt_pass_tile(const NttArgs &a, int bx, int by, u64 *lds)
 {
-    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile<V>::LOG - LOGM : -1;
+    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile::LOG - LOGM : -1;
     ntt_body_load<STRIDED, INVERSE, CM, CC>(a, bx, by, threadIdx.x, lds);
     __syncthreads();
-    if (!(a.probe & 4)) {  // probe bit 2: timing probe that skips the butterflies (memory pattern only)
-        if constexpr (!INVERSE) {
-            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, true>(a, bx, by, lds);
-            else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, false>(a, bx, by, lds);
-        } else {
-            if (a.lazy8) NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM, true>(a, bx, by, lds);
-            else NttRounds<V, LOGM, STRIDED, INVERSE, CC>::template inv<NttSchedV<V, LOGM>::R - 1, LOGM, false>(a, bx, by, lds);
-        }
-    }
+    ntt_tile_rounds<LOGM, STRIDED, INVERSE, CC>(a, bx, by, lds);
     ntt_body_store<STRIDED, INVERSE, CM, CC>(a, bx, by, threadIdx.x, lds);
 }
 
-// V = 0: 4096-point tiles (bulk launches); V = 1: 2048-point tiles -- twice the workgroups, half the lifetime each,
-// used when a launch would not even fill the 1024 resident workgroup slots once (latency-bound small batches).
-// FULL: the tile is 2^LOGM points x 2^(tile log - LOGM) columns (every launch with N >= 4096) -> geometry folds into constants
-template <int V, int LOGM, bool STRIDED, bool INVERSE, bool FULL>
+// FULL: the tile is 2^LOGM points x 2^(12 - LOGM) columns (every launch with N >= 4096) -> geometry folds into constants
+template <int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
 {
-    __shared__ u64 lds[NttLds<V>::ELEMS];
-    ntt_pass_tile<V, LOGM, STRIDED, INVERSE, FULL>(a, NTT_BX(a), NTT_BY(a), lds);
+    __shared__ u64 lds[NttLds::ELEMS];
+    ntt_pass_tile<LOGM, STRIDED, INVERSE, FULL>(a, NTT_BX(a), NTT_BY(a), lds);
 }
 // Two independent batches of the same pass in ONE grid (polynomials [0, a1.count) use a1, the rest a2): a small batch
 // rides in the tail of a big one instead of paying a launch of its own that cannot fill the 1024 workgroup slots.
@@ -153,7 +120,7 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_kernel(NttArgs a)
 template <int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass2_kernel(NttArgs a1, NttArgs a2)
 {
-    __shared__ u64 lds[NttLds<0>::ELEMS];
+    __shared__ u64 lds[NttLds::ELEMS];
     const int by = NTT_BY(a1);
     const bool second = by >= a1.count;
     // Selecting between the two by-value blocks would copy them to scratch; index the kernarg segment instead (a1 at
@@ -162,101 +129,29 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass2_kernel(NttArgs a1, N
     typedef __attribute__((address_space(4))) const NttArgs *args_ptr;
     (void)a2;
     const args_ptr pa = (args_ptr)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + (second ? sizeof(NttArgs) : 0));
-    ntt_pass_tile<0, LOGM, STRIDED, INVERSE, FULL>(*(const NttArgs *)pa, NTT_BX(a1), second ? by - a1.count : by, lds);
+    ntt_pass_tile<LOGM, STRIDED, INVERSE, FULL>(*(const NttArgs *)pa, NTT_BX(a1), second ? by - a1.count : by, lds);
 }
 
-static int g_small_wgs = -1;
-template <int V, bool STRIDED, bool INVERSE>
-static void launch_pass_v(NttArgs a, int logm, int other, hipStream_t st)
+template <bool STRIDED, bool INVERSE>
+static void launch_pass(NttArgs a, int logm, int other, hipStream_t st)
 {
     a.logm = logm;
-    int logc = NttTile<V>::LOG - logm;
+    int logc = NttTile::LOG - logm;
     if (logc > other) logc = other;
     a.logc = logc;
     a.tiles_log = other - logc;
     dim3 grid((unsigned)(((size_t)a.count) << a.tiles_log));
-    static int dyn_lds = -1;  // occupancy probe: extra dynamic LDS per workgroup (HHE_NTT_DYNLDS bytes)
-    if (dyn_lds < 0) { const char *e = getenv("HHE_NTT_DYNLDS"); dyn_lds = e ? atoi(e) : 0; }
-    const bool full = logc == NttTile<V>::LOG - logm;
-#define NTT_LAUNCH(M_)                                                                                                           \
-    case M_:                                                                                                                     \
-        if (full) hipLaunchKernelGGL((ntt_pass_kernel<V, M_, STRIDED, INVERSE, true>), grid, dim3(NTT_THREADS), dyn_lds, st, a); \
-        else hipLaunchKernelGGL((ntt_pass_kernel<V, M_, STRIDED, INVERSE, false>), grid, dim3(NTT_THREADS), dyn_lds, st, a);     \
+    const bool full = logc == NttTile::LOG - logm;
+#define NTT_LAUNCH(M_)                                                                                                     \
+    case M_:                                                                                                               \
+        if (full) hipLaunchKernelGGL((ntt_pass_kernel<M_, STRIDED, INVERSE, true>), grid, dim3(NTT_THREADS), 0, st, a);    \
+        else hipLaunchKernelGGL((ntt_pass_kernel<M_, STRIDED, INVERSE, false>), grid, dim3(NTT_THREADS), 0, st, a);        \
         break;
     switch (logm) {
         NTT_LAUNCH(5) NTT_LAUNCH(6) NTT_LAUNCH(7) NTT_LAUNCH(8)
     default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", logm); break;
     }
 #undef NTT_LAUNCH
-}
-template <bool STRIDED, bool INVERSE>
-static void launch_pass(const NttArgs &a, int logm, int other, hipStream_t st)
-{
-    if (g_small_wgs < 0) { const char *e = getenv("HHE_NTT_SMALL"); g_small_wgs = e ? atoi(e) : 0; }  // measured: no gain on MI355X, off by default
-    int logc0 = NttTile<0>::LOG - logm;
-    if (logc0 > other) logc0 = other;
-    const long long wgs0 = ((long long)1 << (other - logc0)) * a.count;
-    if (wgs0 < g_small_wgs && (1 << a.logn) > (1 << NttTile<1>::LOG)) launch_pass_v<1, STRIDED, INVERSE>(a, logm, other, st);
-    else launch_pass_v<0, STRIDED, INVERSE>(a, logm, other, st);
-}
-template <int LOGM, int I, int S0>
-static __device__ __forceinline__ void dmac_rounds(const NttArgs &a, int bx, int by, u64 *lds)
-{
-    if constexpr (I < NttSchedV<1, LOGM>::R) {
-        constexpr int RHO = NttSchedV<1, LOGM>::rho(I);
-        ntt_body_round<LOGM, S0, RHO, false, false>(a, bx, by, threadIdx.x, lds);
-        __syncthreads();
-        dmac_rounds<LOGM, I + 1, S0 + RHO>(a, bx, by, lds);
-    }
-}
-template <int LOGM>
-__global__ void __launch_bounds__(NTT_THREADS) digit_mac_kernel(NttArgs a, KsMacArgs mk)
-{
-    __shared__ u64 lds[(1 << NttTile<1>::LOG) + 512];
-    u64 acc0[2 * DMAC_NPAIR], acc1[2 * DMAC_NPAIR];
-#pragma unroll
-    for (int k = 0; k < 2 * DMAC_NPAIR; k++) { acc0[k] = 0; acc1[k] = 0; }
-    const int bxx = NTT_BX(a), byy = NTT_BY(a);
-    const int b = byy / a.K, J = byy % a.K;
-    for (int I = 0; I < a.L; I++) {
-        const int by = (b * a.L + I) * a.K + J;
-        ntt_body_load<false, false>(a, bxx, by, threadIdx.x, lds);
-        __syncthreads();
-        dmac_rounds<LOGM, 0, 0>(a, bxx, by, lds);
-        digit_mac_phase(a, mk, bxx, by, I, threadIdx.x, lds, acc0, acc1);
-        __syncthreads();
-    }
-    digit_mac_store(a, mk, bxx, b * a.L * a.K + J, threadIdx.x, acc0, acc1);
-}
-void k_digit_mac(const NttArgs &a0, const KsMacArgs &mk, rt_stream s)
-{
-    NttArgs a = a0;
-    int n1, n2;
-    ntt_split(a.logn, n1, n2);
-    a.logm = n2;
-    int logc = NttTile<1>::LOG - n2;
-    if (logc > n1) logc = n1;
-    a.logc = logc;
-    a.tiles_log = n1 - logc;
-    dim3 grid((unsigned)(((size_t)mk.B * mk.K) << a.tiles_log));
-    hipStream_t st = (hipStream_t)s;
-    switch (n2) {
-    case 5: hipLaunchKernelGGL((digit_mac_kernel<5>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
-    case 6: hipLaunchKernelGGL((digit_mac_kernel<6>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
-    case 7: hipLaunchKernelGGL((digit_mac_kernel<7>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
-    case 8: hipLaunchKernelGGL((digit_mac_kernel<8>), grid, dim3(NTT_THREADS), 0, st, a, mk); break;
-    default: snprintf(g_rt_err, sizeof(g_rt_err), "unsupported NTT pass size 2^%d", n2); break;
-    }
-}
-void k_ntt_first_pass(const NttArgs &a0, bool inverse, rt_stream s)
-{
-    if (a0.count <= 0) return;
-    NttArgs a = a0;
-    a.lazy8 = 0;  // the consumer (digit_mac_kernel) runs Harvey rounds on [0,4q) inputs
-    int n1, n2;
-    ntt_split(a.logn, n1, n2);
-    if (!inverse) launch_pass<true, false>(a, n1, n2, (hipStream_t)s);
-    else launch_pass<false, true>(a, n2, n1, (hipStream_t)s);
 }
 void k_ntt(const NttArgs &a, bool inverse, rt_stream s)
 {
@@ -276,13 +171,13 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream s)
 template <bool STRIDED, bool INVERSE>
 static void launch_pass2(NttArgs a1, NttArgs a2, int logm, int other, hipStream_t st)
 {
-    int logc = NttTile<0>::LOG - logm;
+    int logc = NttTile::LOG - logm;
     if (logc > other) logc = other;
     a1.logm = a2.logm = logm;
     a1.logc = a2.logc = logc;
     a1.tiles_log = a2.tiles_log = other - logc;
     dim3 grid((unsigned)(((size_t)a1.count + a2.count) << a1.tiles_log));
-    const bool full = logc == NttTile<0>::LOG - logm;
+    const bool full = logc == NttTile::LOG - logm;
 #define NTT_LAUNCH2(M_)                                                                                                   \
     case M_:                                                                                                              \
         if (full) hipLaunchKernelGGL((ntt_pass2_kernel<M_, STRIDED, INVERSE, true>), grid, dim3(NTT_THREADS), 0, st, a1, a2);      \
@@ -357,11 +252,9 @@ template <int MODE> static void launch_ks_mac_t(const KsMacArgs &a, rt_stream s)
     default: LAUNCH1D((ks_mac_t_kernel<4, MODE>), total, s, a); break;
     }
 }
-static int g_ks_generic = -1;
 void k_ks_mac(const KsMacArgs &a, rt_stream s)
 {
-    if (g_ks_generic < 0) { const char *e = getenv("HHE_KS_GENERIC"); g_ks_generic = e ? atoi(e) : 0; }  // A/B switch
-    switch (g_ks_generic ? -1 : ks_mac_mode(a)) {
+    switch (ks_mac_mode(a)) {
     case KS_PLAIN: launch_ks_mac_t<KS_PLAIN>(a, s); break;
     case KS_ACC: launch_ks_mac_t<KS_ACC>(a, s); break;
     case KS_PERM: launch_ks_mac_t<KS_PERM>(a, s); break;

@@ -23,12 +23,6 @@ void *rt_event_create();
 void rt_event_destroy(void *ev);
 int rt_event_record(void *ev, rt_stream s);
 int rt_stream_wait_event(rt_stream s, void *ev);
-// stream capture into an executable graph (launch-bound inner loops); rt_capture_begin returns non-zero when the
-// backend cannot capture (then the caller enqueues directly)
-int rt_capture_begin(rt_stream s);
-void *rt_capture_end(rt_stream s);
-int rt_graph_launch(void *exec, rt_stream s);
-void rt_graph_destroy(void *exec);
 const char *rt_last_error();
 
 // kernels (all asynchronous on `s`)
@@ -37,9 +31,6 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream s);  // runs both passes; a
 void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s);
 // inverse transforms of two batches; the store epilogue of the second may read the results of the first (row passes share a grid)
 void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s);
-void k_ntt_first_pass(const NttArgs &a, bool inverse, rt_stream s);  // only the first pass (intermediate left in a.dst)
-// fused: row pass of the forward digit NTTs (after k_ntt_first_pass into a.dst = T) + key-switch inner product into m.S
-void k_digit_mac(const NttArgs &a, const KsMacArgs &m, rt_stream s);
 void k_elt(const EltArgs &a, int op, rt_stream s);
 void k_galois(const GaloisArgs &a, rt_stream s);
 void k_perm(const PermArgs &a, rt_stream s);

@@ -27,138 +27,66 @@ void *rt_event_create() { static int ev; return &ev; }
 void rt_event_destroy(void *) {}
 int rt_event_record(void *, rt_stream) { return 0; }
 int rt_stream_wait_event(rt_stream, void *) { return 0; }
-int rt_capture_begin(rt_stream) { return -1; }
-void *rt_capture_end(rt_stream) { return nullptr; }
-int rt_graph_launch(void *, rt_stream) { return -1; }
-void rt_graph_destroy(void *) {}
 
-template <int V, int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int S0, bool LAZY8 = false>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int S0, bool LAZY8 = false>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
 {
-    if constexpr (I < NttSchedV<V, LOGM>::R) {
-        constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
+    if constexpr (I < NttSched<LOGM>::R) {
+        constexpr int RHO = NttSched<LOGM>::rho(I);
         for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC>(a, bx, by, t, lds);
-        rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
+        rounds_fwd<LOGM, STRIDED, INVERSE, CC, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
     }
 }
-template <int V, int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int SEND, bool LAZY8 = false>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int SEND, bool LAZY8 = false>
 static void rounds_inv(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (I >= 0) {
-        constexpr int RHO = NttSchedV<V, LOGM>::rho(I);
+        constexpr int RHO = NttSched<LOGM>::rho(I);
         for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC>(a, bx, by, t, lds);
-        rounds_inv<V, LOGM, STRIDED, INVERSE, CC, I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
+        rounds_inv<LOGM, STRIDED, INVERSE, CC, I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
     }
 }
-template <int V, int LOGM, bool STRIDED, bool INVERSE, bool FULL>
+// the register rounds of one pass over a staged tile (a barrier after each round = the end of the thread loop)
+template <int LOGM, bool STRIDED, bool INVERSE, int CC>
+static void tile_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds)
+{
+    if constexpr (!INVERSE) {
+        if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, 0, 0, true>(a, bx, by, lds);
+        else rounds_fwd<LOGM, STRIDED, INVERSE, CC, 0, 0, false>(a, bx, by, lds);
+    }
+    else if (a.lazy8) rounds_inv<LOGM, STRIDED, INVERSE, CC, NttSched<LOGM>::R - 1, LOGM, true>(a, bx, by, lds);
+    else rounds_inv<LOGM, STRIDED, INVERSE, CC, NttSched<LOGM>::R - 1, LOGM, false>(a, bx, by, lds);
+}
+template <int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 static void pass_emu(const NttArgs &a, int gx, int gy)
 {
-    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile<V>::LOG - LOGM : -1;
+    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile::LOG - LOGM : -1;
 #pragma omp parallel
     {
-        std::vector<u64> lds(NttLds<V>::ELEMS);
+        std::vector<u64> lds(NttLds::ELEMS);
 #pragma omp for collapse(2)
         for (int by = 0; by < gy; by++)
             for (int bx = 0; bx < gx; bx++) {
                 for (int t = 0; t < NTT_THREADS; t++) ntt_body_load<STRIDED, INVERSE, CM, CC>(a, bx, by, t, lds.data());
-                if constexpr (!INVERSE) {
-                    if (a.lazy8) rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, 0, 0, true>(a, bx, by, lds.data());
-                    else rounds_fwd<V, LOGM, STRIDED, INVERSE, CC, 0, 0, false>(a, bx, by, lds.data());
-                }
-                else if (a.lazy8) rounds_inv<V, LOGM, STRIDED, INVERSE, CC, NttSchedV<V, LOGM>::R - 1, LOGM, true>(a, bx, by, lds.data());
-                else rounds_inv<V, LOGM, STRIDED, INVERSE, CC, NttSchedV<V, LOGM>::R - 1, LOGM, false>(a, bx, by, lds.data());
+                tile_rounds_emu<LOGM, STRIDED, INVERSE, CC>(a, bx, by, lds.data());
                 for (int t = 0; t < NTT_THREADS; t++) ntt_body_store<STRIDED, INVERSE, CM, CC>(a, bx, by, t, lds.data());
             }
     }
 }
-template <int V, bool STRIDED, bool INVERSE>
-static void launch_pass_v(NttArgs a, int logm, int other)
+template <bool STRIDED, bool INVERSE>
+static void launch_pass(NttArgs a, int logm, int other)
 {
     a.logm = logm;
-    int logc = NttTile<V>::LOG - logm;
+    int logc = NttTile::LOG - logm;
     if (logc > other) logc = other;
     a.logc = logc;
     const int gx = 1 << (other - logc), gy = a.count;
-    const bool full = logc == NttTile<V>::LOG - logm;
-#define PASS_EMU(M_) case M_: if (full) pass_emu<V, M_, STRIDED, INVERSE, true>(a, gx, gy); else pass_emu<V, M_, STRIDED, INVERSE, false>(a, gx, gy); break;
+    const bool full = logc == NttTile::LOG - logm;
+#define PASS_EMU(M_) case M_: if (full) pass_emu<M_, STRIDED, INVERSE, true>(a, gx, gy); else pass_emu<M_, STRIDED, INVERSE, false>(a, gx, gy); break;
     switch (logm) {
     PASS_EMU(5) PASS_EMU(6) PASS_EMU(7) PASS_EMU(8)
     default: fprintf(stderr, "emu: unsupported pass size\n"); abort();
     }
-}
-// same geometry selection as hhe_kernels.hip (HHE_NTT_SMALL: workgroup-count threshold below which 2048-point tiles are used)
-template <bool STRIDED, bool INVERSE>
-static void launch_pass(const NttArgs &a, int logm, int other)
-{
-    const char *e = getenv("HHE_NTT_SMALL");
-    const int small_wgs = e ? atoi(e) : 0;
-    int logc0 = NttTile<0>::LOG - logm;
-    if (logc0 > other) logc0 = other;
-    const long long wgs0 = ((long long)1 << (other - logc0)) * a.count;
-    if (wgs0 < small_wgs && (1 << a.logn) > (1 << NttTile<1>::LOG)) launch_pass_v<1, STRIDED, INVERSE>(a, logm, other);
-    else launch_pass_v<0, STRIDED, INVERSE>(a, logm, other);
-}
-template <int LOGM, int I, int S0>
-static void dmac_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds)
-{
-    if constexpr (I < NttSchedV<1, LOGM>::R) {
-        constexpr int RHO = NttSchedV<1, LOGM>::rho(I);
-        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, false, false>(a, bx, by, t, lds);
-        dmac_rounds_emu<LOGM, I + 1, S0 + RHO>(a, bx, by, lds);
-    }
-}
-template <int LOGM>
-static void digit_mac_emu(const NttArgs &a, const KsMacArgs &mk, int gx, int gy)
-{
-#pragma omp parallel
-    {
-        std::vector<u64> lds((1 << NttTile<1>::LOG) + 512);
-        std::vector<u64> acc0((size_t)NTT_THREADS * 2 * DMAC_NPAIR), acc1((size_t)NTT_THREADS * 2 * DMAC_NPAIR);
-#pragma omp for collapse(2)
-        for (int y = 0; y < gy; y++)
-            for (int bx = 0; bx < gx; bx++) {
-                std::fill(acc0.begin(), acc0.end(), 0);
-                std::fill(acc1.begin(), acc1.end(), 0);
-                const int b = y / a.K, J = y % a.K;
-                for (int I = 0; I < a.L; I++) {
-                    const int by = (b * a.L + I) * a.K + J;
-                    for (int t = 0; t < NTT_THREADS; t++) ntt_body_load<false, false>(a, bx, by, t, lds.data());
-                    dmac_rounds_emu<LOGM, 0, 0>(a, bx, by, lds.data());
-                    for (int t = 0; t < NTT_THREADS; t++)
-                        digit_mac_phase(a, mk, bx, by, I, t, lds.data(), &acc0[(size_t)t * 2 * DMAC_NPAIR], &acc1[(size_t)t * 2 * DMAC_NPAIR]);
-                }
-                for (int t = 0; t < NTT_THREADS; t++)
-                    digit_mac_store(a, mk, bx, b * a.L * a.K + J, t, &acc0[(size_t)t * 2 * DMAC_NPAIR], &acc1[(size_t)t * 2 * DMAC_NPAIR]);
-            }
-    }
-}
-void k_digit_mac(const NttArgs &a0, const KsMacArgs &mk, rt_stream)
-{
-    NttArgs a = a0;
-    int n1, n2;
-    ntt_split(a.logn, n1, n2);
-    a.logm = n2;
-    int logc = NttTile<1>::LOG - n2;
-    if (logc > n1) logc = n1;
-    a.logc = logc;
-    const int gx = 1 << (n1 - logc), gy = mk.B * mk.K;
-    switch (n2) {
-    case 5: digit_mac_emu<5>(a, mk, gx, gy); break;
-    case 6: digit_mac_emu<6>(a, mk, gx, gy); break;
-    case 7: digit_mac_emu<7>(a, mk, gx, gy); break;
-    case 8: digit_mac_emu<8>(a, mk, gx, gy); break;
-    default: abort();
-    }
-}
-void k_ntt_first_pass(const NttArgs &a0, bool inverse, rt_stream)
-{
-    if (a0.count <= 0) return;
-    NttArgs a = a0;
-    a.lazy8 = 0;
-    int n1, n2;
-    ntt_split(a.logn, n1, n2);
-    if (!inverse) launch_pass<true, false>(a, n1, n2);
-    else launch_pass<false, true>(a, n2, n1);
 }
 void k_ntt(const NttArgs &a, bool inverse, rt_stream)
 {
@@ -190,8 +118,7 @@ template <int MODE> static void ks_mac_t_emu(const KsMacArgs &a)
 }
 void k_ks_mac(const KsMacArgs &a, rt_stream)
 {
-    const char *e = getenv("HHE_KS_GENERIC");
-    switch (e && atoi(e) ? -1 : ks_mac_mode(a)) {
+    switch (ks_mac_mode(a)) {
     case KS_PLAIN: ks_mac_t_emu<KS_PLAIN>(a); break;
     case KS_ACC: ks_mac_t_emu<KS_ACC>(a); break;
     case KS_PERM: ks_mac_t_emu<KS_PERM>(a); break;

@@ -224,11 +224,11 @@ def test_reference_n65536_29_prime_context_is_accepted(orc, api, emu_lib, mem):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MACFUSE": "1"}, {"HHE_SIDE": "1"},
-    {"HHE_DIGIT_SUB": "1", "HHE_CHUNK": "4"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"}, {"HHE_GRAPH": "0"},
+    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MERGE": "0"}, {"HHE_LAZY8": "0"},
+    {"HHE_MATMUL": "0", "HHE_STREAMS": "1"},
 ])
 def test_every_execution_knob_gives_the_same_words(orc, api, emu_lib, mem, small, monkeypatch, knobs):
-    """chunking / streams / fused-MAC / side-stream / sub-batching / graph knobs only change scheduling"""
+    """chunking / streams / grid merging / range folding / op-by-op schedule only change scheduling"""
     pt = [(3 * i + 1) % 256 for i in range(300)]
     cw, ncw = small.sym_blocks(orc, pt)
     refs = [small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[b, :ncw[b]], b) for b in range(3)]
@@ -241,14 +241,6 @@ def test_every_execution_knob_gives_the_same_words(orc, api, emu_lib, mem, small
     res = mem.to_host(out)
     for b in range(3):
         assert (res[b] == refs[b]).all(), knobs
-
-
-def test_small_tile_geometry_of_the_ntt_passes(orc, api, emu_lib, mem, monkeypatch):
-    """HHE_NTT_SMALL selects 2048-point tiles for launches with few workgroups: same transform"""
-    monkeypatch.setenv("HHE_NTT_SMALL", "100000")
-    for logn, bits in ((12, [55] * 2), (13, [60] * 2), (15, [60] * 2)):
-        q = orc.coeff_modulus_create(1 << logn, bits)
-        pc.check_ntt(api.Context(logn, q, T, lib=emu_lib), orc.Oracle(logn, q, T), mem, seed=logn)
 
 
 def test_edge_cases_single_word_block_and_large_block_counter(orc, api, emu_lib, mem, small):
