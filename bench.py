@@ -46,6 +46,49 @@ def synthetic_keys(rng, q, n):
     return k
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: this process never touches the GPU; it starts N fresh rank processes
+    (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment), lets rank 0 print the one JSON line on the
+    inherited stdout and fails if any rank fails."""
+    import socket
+    import subprocess
+    if "HHE_BENCH_DEVICE" not in os.environ and "HHE_LIB" not in os.environ:
+        import torch
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < n_ranks:
+            print(f"bench.py: --gpus {n_ranks} requested but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending and rc == 0:
+            for p in list(pending):
+                try:
+                    r = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if r != 0:
+                    rc = r
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                if rc:
+                    p.kill()  # a failed rank leaves the others stuck at the barrier
+                p.wait()
+    if rc:
+        print(f"bench.py: a rank failed (exit code {rc})", file=sys.stderr)
+    return 1 if rc else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,16 +101,16 @@ def main():
                     help="config2: N=2^15, 4x60-bit (BASELINE metric); default16384: the reference's defaults N=2^14, BFVDefault 9 primes")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-blocks-per-thread", type=int, default=2)
-    ap.add_argument("--graphs", type=int, default=0, choices=[0, 1],
-                    help="1: hipGraph replay of the matmul loop (library opt-in HHE_GRAPH=1, valid for transcipher-only processes); 0: library default")
     args = ap.parse_args()
 
-    if args.graphs:
-        os.environ["HHE_GRAPH"] = "1"  # read by hhe_ctx_create
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     import torch
     sh = importlib.import_module(PKG + ".sharding")
     api = importlib.import_module(PKG + ".api")
     rank, world, local_rank = sh.rank_world()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL; used for the barrier / time reduction only (HHE_BENCH_BACKEND=gloo: rehearsal of the N>1 path on one GPU)
@@ -135,7 +178,7 @@ def main():
     # of one rotation step of the pipeline at its chunk size: forward over the 32x12 digit polys together with the 32x3
     # c0 limbs of the previous step (one shared grid), inverse over the 32x2 special limbs and over the 32x3 c1 limbs
     # -> 6 kernel launches (2 passes each)
-    CH = 128 if os.environ.get("HHE_GRAPH", "0") != "1" else 32  # the library's chunk size in this mode
+    CH = 128  # the library's chunk size
     mix = [(CH * L * K + CH * L, False), (CH * 2, True), (CH * L, True)]
     npoly = sum(m[0] for m in mix)
     scratch = torch.zeros((CH * L * K + CH * L, n), dtype=torch.int64, device=dev)
@@ -172,8 +215,7 @@ def main():
                                    ("BASELINE config 2: N=2^15, coeff_modulus 4x60-bit (L=3,K=4), t=65537, "
                                     f"batch-{B} independent 128-word PASTA-3 blocks per GPU, block counter 0") if args.workload == "config2" else
                                    (f"MNIST-shaped: N=2^15, 4x60-bit, t=65537, batch-{B} blocks per GPU = 784-word samples x 7 block counters (last block 16 words)"),
-                       "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective",
-                       "graph_replay": os.environ.get("HHE_GRAPH", "0") == "1"},
+                       "batch_per_gpu": B, "sharding": f"{world} rank(s), independent items, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_b256_final2.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                          "kernel": "hhe_pasta3_transcipher (whole path; SURVEY 8d A_block)",

@@ -358,6 +358,20 @@ int matmul_diagonal(hhe_ctx *c, int layer, const u64 *const *d_diag_ptrs, size_t
     return HHE_OK;
 }
 
+// Shoup quotients floor(key * 2^64 / q_J) of a key-switch key ([L][2][K][N], as the key), built on first use by the
+// fused row kernel and cached per Galois element
+int ensure_key_shoup(hhe_ctx *c, u32 elt, const u64 *key, const u64 **out)
+{
+    auto it = c->d_gk_shoup.find(elt);
+    if (it != c->d_gk_shoup.end()) { *out = it->second; return HHE_OK; }
+    DevBuf t(c->ksk_words() * 8);
+    if (!t.p) return dev_fail("key Shoup table alloc");
+    op_elt(c, ELT_SHOUP, key, nullptr, t.w(), (size_t)c->L * 2 * c->K, 0, c->K);
+    if (rt_sync(c->w->stream)) return dev_fail("key Shoup table");
+    *out = c->d_gk_shoup[elt] = t.release();
+    return HHE_OK;
+}
+
 // PASTA_SEAL::diagonal (pasta_3_seal.cpp:370-413) as a fused pipeline: same ciphertext words as the
 // op-by-op schedule, 20 transforms per rotation step instead of 35 (DESIGN.md "fused matmul").
 //  - c0 stays in NTT form across the 127 rotate_rows(-1); c1 is kept in coefficient form because the
@@ -399,10 +413,42 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     // the c0 branch of step i+1, and like the digit transforms of step i+1 it depends on nothing later than the inverse
     // transforms of step i: both go into one grid (k_ntt2_fwd).
     const bool merge = c->merge_fwd != 0;
+    // N >= 4096: the row pass of the digit transforms, the key inner product and the inverse row pass run as ONE kernel
+    // (ks_row_kernel): T and the sums that are inverse-transformed next never reach memory
+    const bool rowk = k_ks_row_supported(c->logn);
+    const u64 *key_s = nullptr;
+    if (rowk) {
+        int rc = ensure_key_shoup(c, g, key, &key_s);
+        if (rc) return rc;
+    }
     NttArgs k5;
     bool k5_pending = false;
     for (int i = 0; i < PASTA_T - 1; ++i) {
         const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
+        if (rowk) {
+            NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
+            a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+            a.store_op = STORE_LAZY;
+            // strided pass of the digit transforms with the c0 branch of the previous step in the same grid; the row pass
+            // of that c0 branch then rides in the grid of ks_row_kernel (S_0 alternates between the two halves of ws_S,
+            // so the c0 branch reads the previous step's while this step's is written)
+            if (k5_pending) k_ntt2_fwd_first(k5, a, c->w->stream);
+            else k_ntt_pass(a, false, false, c->w->stream);
+            KsRowArgs x;
+            memset(&x, 0, sizeof(x));
+            x.key = key; x.key_s = key_s; x.S = c->w->ws_S + (size_t)(i & 1) * K * n; x.U1 = scr; x.Usp = r; x.B = (int)B; x.L = L; x.K = K;
+            x.acc = accp1; x.mul_ptrs = d_pdiag_ptrs; x.mul_shift = shift;
+            k_ks_row(a, x, k5_pending ? &k5 : nullptr, c->w->stream);
+            k5_pending = false;
+            // second (strided) inverse passes: r_k = INTT(S_k[special]) + floor(q_sp/2); c1 of the next state through the
+            // mod-down epilogue and the Galois map
+            NttArgs as = ntt_args(c, r, r, B * 2, K - 1, 1);
+            as.store_op = STORE_RSP;
+            k_ntt_pass(as, true, true, c->w->stream);
+            NttArgs a1 = ntt_args(c, scr, scr, B * L, 0, L);
+            a1.store_op = STORE_KS1; a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = g;
+            k_ntt_pass(a1, true, true, c->w->stream);
+        } else {
         {   // digits T[I][J] = NTT_J(d[I] mod q_J) and S_k[J] = sum_I T[I][J] * key[I][k][J]; the I = J digit also feeds
             // the plain product
             NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
@@ -426,12 +472,14 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             if (merge) k_ntt2_inv(a, a1, c->w->stream);
             else { k_ntt(a, true, c->w->stream); k_ntt(a1, true, c->w->stream); }
         }
+        }
         {   // c0 of the next state in NTT form + permuted-frame product of the current c0
             NttArgs a = ntt_args(c, r, scr2, B * L, 0, L);
             a.src_item_polys = L; a.src_item_stride = 2 * n; a.src_div = L; a.load_op = LOAD_RNEG;
-            a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.aux_r = c->w->ws_S; a.acc = accp0;
+            a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.acc = accp0;
+            a.aux_r = c->w->ws_S + (rowk ? (size_t)(i & 1) * K * n : 0);
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g;
-            if (merge) { k5 = a; k5_pending = true; }  // launched in the grid of the next step's digit transforms
+            if (merge || rowk) { k5 = a; k5_pending = true; }  // launched in the grid of the next step's digit transforms
             else k_ntt(a, false, c->w->stream);
         }
         cur ^= 1;

@@ -85,7 +85,7 @@ struct NttArgs {
     KsConsts ks;
 };
 
-enum EltOp { ELT_ADD = 0, ELT_SUB = 1, ELT_NEG = 2, ELT_MUL = 3, ELT_MAC = 4, ELT_COPY = 5, ELT_BCAST = 6 };
+enum EltOp { ELT_ADD = 0, ELT_SUB = 1, ELT_NEG = 2, ELT_MUL = 3, ELT_MAC = 4, ELT_COPY = 5, ELT_BCAST = 6, ELT_SHOUP = 7 };
 
 struct EltArgs {  // element-wise kernels over [count][N] polys, modulus = mod_base + p % mod_cycle
     const u64 *a, *b;
@@ -122,6 +122,23 @@ struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
     u32 perm_elt;
     const u64 *corr;  // [2][K][N]
 };
+// Fused key-switch row kernel (ks_row_kernel): for one (item b, key limb J, row tile) it runs the forward ROW pass of the
+// L digit transforms T[b][I][J] (their strided pass has already run), multiplies each finished tile with key[I][0..1][J]
+// (Shoup products, 64-bit lazy sums kept in registers), and runs the inverse ROW pass on the sums that are
+// inverse-transformed next -- so neither T nor S_1 / S_k[special] makes a round trip through memory.
+struct KsRowArgs {
+    const u64 *key;      // [L][2][K][N]
+    const u64 *key_s;    // Shoup quotients floor(key * 2^64 / q_J), same layout
+    u64 *S;              // [B][2][K][N]: only S_0[j], j < L, is written (NTT form, canonical) -- the c0 branch reads it
+    u64 *U1;             // [B][L][N]: inverse row pass of S_1[j], j < L
+    u64 *Usp;            // [B][2][N]: inverse row pass of S_0[special], S_1[special]
+    int B, L, K;
+    // fused matmul: acc[b][J][n] += T[b][J][J][n] * mul_ptrs[b][mul_shift + J*N + n] for J < L (the I = J digit)
+    u64 *acc;
+    const u64 *const *mul_ptrs;
+    size_t mul_shift;
+};
+
 // Correction of the shared-digit key switch (DESIGN.md "FC rotation trie"): the digit d_I of galois_g(c1) differs from
 // galois_g applied mod q_J to the digit of c1 by q_I at every sign-flipped, non-zero coefficient, so
 //   corr[k][J] = NTT_J(s_g) * sum_{I != J} (q_I mod q_J) * key_g[I][k][J]     (s_g = 0/1 polynomial of the flipped positions)

@@ -405,6 +405,7 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
     for (auto &p : c->d_rk_slot) rt_free(p);
     for (auto &kv : c->d_gk) rt_free(kv.second);
     for (auto &kv : c->d_gk_corr) rt_free(kv.second);
+    for (auto &kv : c->d_gk_shoup) rt_free(kv.second);
     rt_free(c->d_feistel_mask);
     rt_free(c->d_tables); rt_free(c->d_mods); rt_free(c->d_behz); rt_free(c->d_slot_map);
     delete c;
@@ -474,6 +475,8 @@ extern "C" int hhe_set_galois_key(hhe_ctx *c, uint32_t elt, const uint64_t *ksk)
     if (!c || !ksk || !(elt & 1) || elt >= 2 * c->n) { hhe_set_error("hhe_set_galois_key: invalid Galois element"); return HHE_ERR_INVALID; }
     auto corr = c->d_gk_corr.find(elt);  // derived from the key being replaced
     if (corr != c->d_gk_corr.end()) { rt_sync(c->lanes[0].stream); rt_free(corr->second); c->d_gk_corr.erase(corr); }
+    auto sh = c->d_gk_shoup.find(elt);
+    if (sh != c->d_gk_shoup.end()) { rt_sync(c->lanes[0].stream); rt_free(sh->second); c->d_gk_shoup.erase(sh); }
     u64 *&slot = c->d_gk[elt];
     return upload_key(c, slot, ksk);
 }

@@ -75,6 +75,7 @@ struct hhe_ctx {
     u64 *d_rk = nullptr;                       // slot 0 (transciphering)
     u64 *d_rk_slot[HHE_RELIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     std::map<u32, u64 *> d_gk;
+    std::map<u32, u64 *> d_gk_shoup;           // per Galois key: Shoup quotients of the key words (fused row kernel), built on first use
     std::map<u32, u64 *> d_gk_corr;            // per Galois key: shared-digit correction [2][K][N] (KsCorrArgs), built on first FC use
 
     // PASTA public tables

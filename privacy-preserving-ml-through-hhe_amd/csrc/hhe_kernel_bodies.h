@@ -16,11 +16,16 @@ constexpr int NTT_THREADS = 256;
 // 4096-point tiles, radix-16/8 register rounds (16 points per lane).  (A 2048-point / radix-8 geometry at 5-8 waves per SIMD
 // was measured in round 1: butterflies-only 0.31 vs 0.28 us per transform, and removed.)
 struct NttTile { static constexpr int LOG = 12; };
-template <int LOGM> struct NttSched;  // register-radix schedule per sub-transform size
-template <> struct NttSched<5> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
-template <> struct NttSched<6> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
-template <> struct NttSched<7> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 4 : 3; } };
-template <> struct NttSched<8> { static constexpr int R = 2; static constexpr int rho(int i) { return 4; } };
+// register-radix schedule per sub-transform size and workgroup width: T = 256 lanes hold 16 points each (radix-16/8
+// rounds), T = 512 lanes hold 8 points each (radix-8/4 rounds: half the registers per lane, one more round)
+template <int LOGM, int T = NTT_THREADS> struct NttSched;
+template <> struct NttSched<5, 256> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
+template <> struct NttSched<6, 256> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
+template <> struct NttSched<7, 256> { static constexpr int R = 2; static constexpr int rho(int i) { return i == 0 ? 4 : 3; } };
+template <> struct NttSched<8, 256> { static constexpr int R = 2; static constexpr int rho(int i) { return 4; } };
+template <> struct NttSched<6, 512> { static constexpr int R = 2; static constexpr int rho(int i) { return 3; } };
+template <> struct NttSched<7, 512> { static constexpr int R = 3; static constexpr int rho(int i) { return i == 0 ? 3 : 2; } };
+template <> struct NttSched<8, 512> { static constexpr int R = 3; static constexpr int rho(int i) { return i == 2 ? 2 : 3; } };
 struct NttLds { static constexpr int ELEMS = (1 << NttTile::LOG) + 512; };  // rows of pitch C+1
 
 HD u32 bitrev_n(u32 v, int bits)
@@ -142,7 +147,7 @@ template <bool FIRST> HD U2 ntt_load_op(const NttArgs &a, const ModDev &m, int p
 }
 // full tiles (every launch with N >= 4096): all NP global loads of a lane are issued before the first LDS write, so
 // a workgroup's load phase costs one memory round trip instead of NP
-template <bool STRIDED, bool INVERSE, int NP>
+template <bool STRIDED, bool INVERSE, int NP, int T = NTT_THREADS>
 HD void ntt_load_full(const NttArgs &a, const NttGeom &g, const ModDev &m, const u64 *src, int tid, u64 *lds)
 {
     constexpr bool FIRST = (STRIDED != INVERSE);
@@ -151,7 +156,7 @@ HD void ntt_load_full(const NttArgs &a, const NttGeom &g, const ModDev &m, const
 #pragma unroll
     for (int k = 0; k < NP; k++) {
         int x, lane, gi;
-        ntt_pair<STRIDED>(a, g, tid + k * NTT_THREADS, x, lane, gi, l0[k], l1[k]);
+        ntt_pair<STRIDED>(a, g, tid + k * T, x, lane, gi, l0[k], l1[k]);
         v[k] = ld2_stream(src + gi);
     }
 #pragma unroll
@@ -162,7 +167,7 @@ HD void ntt_load_full(const NttArgs &a, const NttGeom &g, const ModDev &m, const
     }
 }
 
-template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1>
+template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1, int T = NTT_THREADS>
 HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
     constexpr bool FIRST = (STRIDED != INVERSE);
@@ -174,9 +179,9 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
         src = a.src + (size_t)(g.poly / ip) * a.src_item_stride + (size_t)((g.poly % ip) / a.src_div) * g.n;
     } else src = a.dst + (size_t)g.poly * g.n;
     const int E2 = (g.M * g.C) >> 1;
-    if (E2 == 8 * NTT_THREADS) { ntt_load_full<STRIDED, INVERSE, 8>(a, g, m, src, tid, lds); return; }
-    if (E2 == 4 * NTT_THREADS) { ntt_load_full<STRIDED, INVERSE, 4>(a, g, m, src, tid, lds); return; }
-    for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) {
+    if (E2 == 8 * T) { ntt_load_full<STRIDED, INVERSE, 8, T>(a, g, m, src, tid, lds); return; }
+    if (E2 == 4 * T) { ntt_load_full<STRIDED, INVERSE, 4, T>(a, g, m, src, tid, lds); return; }
+    for (int e2 = tid; e2 < E2; e2 += T) {
         int x, lane, gi, l0, l1;
         ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
         const U2 v = ntt_load_op<FIRST>(a, m, g.poly, ld2(src + gi));
@@ -191,7 +196,7 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 // invariant).  LAZY8 (all moduli of the launch < 2^60, i.e. 16q <= 2^64): fold once per round instead -- X >= 8q ? X - 8q
 // at the round's first stage, then up to four stages grow it to < 16q, which still fits 64 bits.  Saves RHO-1 of every RHO
 // conditional subtractions; the values stay congruent, so every fully reduced result is unchanged.
-template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1>
+template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS>
 HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
     const NttGeom g = ntt_geom<(CC >= 0 ? LOGM : -1), CC>(a, bx, by);
@@ -202,7 +207,7 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
     constexpr int LO_BITS = LOGM - S0 - RHO;
     constexpr int RAD = 1 << RHO;
     const int groups = (g.M >> RHO) * g.C;
-    for (int grp = tid; grp < groups; grp += NTT_THREADS) {
+    for (int grp = tid; grp < groups; grp += T) {
         const int lane = grp & (g.C - 1);
         const int sub = grp >> g.logc;
         const int hi = sub >> LO_BITS;
@@ -395,7 +400,7 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
 
 // NP pairs per lane, compile-time: the epilogue operands of G pairs are fetched before the first of them is stored (G > 1
 // trades registers for memory-level parallelism)
-template <bool STRIDED, bool INVERSE, int NP>
+template <bool STRIDED, bool INVERSE, int NP, int T = NTT_THREADS>
 HD void ntt_store_full(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 *dst, size_t pbase, int tid, const u64 *lds)
 {
 #ifndef NTT_STORE_G
@@ -409,14 +414,14 @@ HD void ntt_store_full(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
 #pragma unroll
         for (int k = 0; k < G; k++) {
             int x, lane;
-            ntt_pair<STRIDED>(a, g, tid + (k0 + k) * NTT_THREADS, x, lane, gi[k], l0[k], l1[k]);
+            ntt_pair<STRIDED>(a, g, tid + (k0 + k) * T, x, lane, gi[k], l0[k], l1[k]);
             pre[k] = ntt_store_fetch<STRIDED, INVERSE>(a, g, pbase, gi[k]);
         }
 #pragma unroll
         for (int k = 0; k < G; k++) ntt_store_pair<STRIDED, INVERSE>(a, g, m, dst, pbase, gi[k], l0[k], l1[k], pre[k], lds);
     }
 }
-template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1>
+template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1, int T = NTT_THREADS>
 HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds)
 {
     const NttGeom g = ntt_geom<CM, CC>(a, bx, by);
@@ -424,9 +429,9 @@ HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds
     u64 *dst = a.dst + (size_t)g.poly * g.n;
     const size_t pbase = (size_t)g.poly * g.n;
     const int E2 = (g.M * g.C) >> 1;
-    if (E2 == 8 * NTT_THREADS) { ntt_store_full<STRIDED, INVERSE, 8>(a, g, m, dst, pbase, tid, lds); return; }  // full tiles
-    if (E2 == 4 * NTT_THREADS) { ntt_store_full<STRIDED, INVERSE, 4>(a, g, m, dst, pbase, tid, lds); return; }
-    for (int e2 = tid; e2 < E2; e2 += NTT_THREADS) {
+    if (E2 == 8 * T) { ntt_store_full<STRIDED, INVERSE, 8, T>(a, g, m, dst, pbase, tid, lds); return; }  // full tiles
+    if (E2 == 4 * T) { ntt_store_full<STRIDED, INVERSE, 4, T>(a, g, m, dst, pbase, tid, lds); return; }
+    for (int e2 = tid; e2 < E2; e2 += T) {
         int x, lane, gi, l0, l1;
         ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
         const StorePre pre = ntt_store_fetch<STRIDED, INVERSE>(a, g, pbase, gi);
@@ -445,6 +450,7 @@ HD void elt_body(const EltArgs &a, int op, size_t gid)
     const ModDev &m = a.mods[a.mod_base + (int)(p % a.mod_cycle)];
     const size_t bp = a.b_cycle ? p % a.b_cycle : p;
     const u64 x = op == ELT_BCAST ? 0 : a.a[gid];
+    if (op == ELT_SHOUP) { a.out[gid] = shoup_quotient(x, m); return; }
     u64 r;
     switch (op) {
     case ELT_BCAST: r = a.b[bp * n + i]; break;
@@ -624,6 +630,89 @@ HD void ks_corr_body(const KsCorrArgs &a, size_t gid)
     for (int I = 0; I < a.L; I++)
         if (I != J) sum = addmod(sum, mulmod(a.key[(((size_t)I * 2 + k) * a.K + J) * n + x], a.qmod[I * a.K + J], m), m.q);
     a.corr[gid] = mulmod(sum, a.shat[(size_t)J * n + x], m);
+}
+
+// ------------------------------------------------------------------ fused key-switch row kernel (KsRowArgs)
+// Phases of one workgroup (b, J, row tile); fa / ia are the argument blocks of the forward / inverse row pass whose
+// geometry and moduli the shared round bodies read (poly index `by` only selects the modulus there).
+#ifndef KSROW_TL
+#define KSROW_TL 11
+#endif
+constexpr int KSROW_TILE_LOG = KSROW_TL;                             // points per tile of this kernel (log2)
+constexpr int KSROW_THREADS = (1 << KSROW_TILE_LOG) / 8;             // 8 points per lane: 2 x 8 lazy sums + a radix-8 round fit the 128-VGPR budget of 4 waves per SIMD
+constexpr int KSROW_SCHED = 512;                                     // NttSched selector of the 8-points-per-lane (radix-8/4) schedules
+constexpr int KSROW_NP = (1 << KSROW_TILE_LOG) / 2 / KSROW_THREADS;  // pairs per lane of a tile
+constexpr int KSROW_LDS = (1 << KSROW_TILE_LOG) + 512;
+// after the forward rounds of digit I: acc_k[pair] += T * key[I][k][J]   (Shoup product in [0,2q); sums folded below 2q
+// after every fourth digit, so they never exceed 8q < 2^64)
+template <int CM, int CC>
+HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, int J, int I, int tid, const u64 *lds, u64 *acc0, u64 *acc1)
+{
+    const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
+    const ModDev &m = fa.mods[J];
+    const u64 q = m.q, q2 = q << 1, q4 = q << 2;
+    const size_t kofs = (((size_t)I * 2) * x.K + J) * g.n, kstep = (size_t)x.K * g.n;
+    const bool diag = x.acc && I == J;
+    const u64 *dptr = diag ? x.mul_ptrs[b] + x.mul_shift + (size_t)J * g.n : nullptr;
+    u64 *ap = diag ? x.acc + ((size_t)b * x.L + J) * g.n : nullptr;
+#pragma unroll
+    for (int k = 0; k < KSROW_NP; k++) {
+        int xx, lane, gi, l0, l1;
+        ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
+        const U2 k0 = ld2(x.key + kofs + gi), k0s = ld2(x.key_s + kofs + gi);
+        const U2 k1 = ld2(x.key + kofs + kstep + gi), k1s = ld2(x.key_s + kofs + kstep + gi);
+        const u64 v0 = lds[l0], v1 = lds[l1];
+        acc0[2 * k] += shoup_lazy(v0, k0.a, k0s.a, q);
+        acc0[2 * k + 1] += shoup_lazy(v1, k0.b, k0s.b, q);
+        acc1[2 * k] += shoup_lazy(v0, k1.a, k1s.a, q);
+        acc1[2 * k + 1] += shoup_lazy(v1, k1.b, k1s.b, q);
+        if ((I & 3) == 3) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                u64 &a0 = acc0[2 * k + e], &a1 = acc1[2 * k + e];
+                a0 -= (a0 >= q4) ? q4 : 0; a0 -= (a0 >= q2) ? q2 : 0;
+                a1 -= (a1 >= q4) ? q4 : 0; a1 -= (a1 >= q2) ? q2 : 0;
+            }
+        }
+        if (diag) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product (lazy input, Barrett accepts it)
+            const U2 d = ld2(dptr + gi);
+            U2 ac = ld2(ap + gi);
+            ac.a = addmod(ac.a, mulmod(v0, d.a, m), q);
+            ac.b = addmod(ac.b, mulmod(v1, d.b, m), q);
+            st2(ap + gi, ac);
+        }
+    }
+}
+// sums -> LDS in [0,2q) (input range of the inverse rounds); optionally also canonical to global (S_0[j])
+template <int CM, int CC>
+HD void ks_row_flush_phase(const NttArgs &fa, int bx, int J, int tid, u64 *lds, const u64 *acc, u64 *canon_out)
+{
+    const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
+    const u64 q = fa.mods[J].q, q2 = q << 1, q4 = q << 2;
+#pragma unroll
+    for (int k = 0; k < KSROW_NP; k++) {
+        int xx, lane, gi, l0, l1;
+        ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
+        u64 v0 = acc[2 * k], v1 = acc[2 * k + 1];
+        v0 -= (v0 >= q4) ? q4 : 0; v0 -= (v0 >= q2) ? q2 : 0;
+        v1 -= (v1 >= q4) ? q4 : 0; v1 -= (v1 >= q2) ? q2 : 0;
+        if (canon_out) {
+            v0 -= (v0 >= q) ? q : 0; v1 -= (v1 >= q) ? q : 0;
+            st2(canon_out + gi, U2{v0, v1});
+        } else { lds[l0] = v0; lds[l1] = v1; }
+    }
+}
+// inverse row pass output (first inverse pass: plain stream store of the tile)
+template <int CM, int CC>
+HD void ks_row_store_phase(const NttArgs &fa, int bx, int J, int tid, const u64 *lds, u64 *out)
+{
+    const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
+#pragma unroll
+    for (int k = 0; k < KSROW_NP; k++) {
+        int xx, lane, gi, l0, l1;
+        ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
+        st2_stream(out + gi, U2{lds[l0], lds[l1]});
+    }
 }
 
 // closes the leaf sums of the FC rotation trie: gid over [B][2][L][N]

@@ -57,17 +57,18 @@ int rt_stream_wait_event(rt_stream s, void *ev) { return rt_check(hipStreamWaitE
 #define NTT_BX(a) ((int)(blockIdx.x & ((1u << (a).tiles_log) - 1)))
 #define NTT_BY(a) ((int)(blockIdx.x >> (a).tiles_log))
 
-// CC = tile columns as a compile-time constant (full tiles) or -1 (ragged tiles of small N: taken from the arguments)
-template <int LOGM, bool STRIDED, bool INVERSE, int CC>
+// CC = tile columns as a compile-time constant (full tiles) or -1 (ragged tiles of small N: taken from the arguments);
+// T = lanes per workgroup (256: radix-16 rounds, 512: radix-8 rounds)
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH = T>
 struct NttRounds {
-    static constexpr int R = NttSched<LOGM>::R;
+    static constexpr int R = NttSched<LOGM, SCH>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
     template <int I, int S0, bool LAZY8 = false>
     static __device__ __forceinline__ void fwd(const NttArgs &a, int bx, int by, u64 *lds)
     {
         if constexpr (I < R) {
-            constexpr int RHO = NttSched<LOGM>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC>(a, bx, by, threadIdx.x, lds);
+            constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T>(a, bx, by, threadIdx.x, lds);
             __syncthreads();
             fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
         }
@@ -76,35 +77,35 @@ struct NttRounds {
     static __device__ __forceinline__ void inv(const NttArgs &a, int bx, int by, u64 *lds)
     {
         if constexpr (I >= 0) {
-            constexpr int RHO = NttSched<LOGM>::rho(I);
-            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC>(a, bx, by, threadIdx.x, lds);
+            constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
+            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC, T>(a, bx, by, threadIdx.x, lds);
             __syncthreads();
             inv<I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
         }
     }
 };
 // the register rounds of one pass over the tile staged in LDS (each round ends with a barrier)
-template <int LOGM, bool STRIDED, bool INVERSE, int CC>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int SCH = T>
 static __device__ __forceinline__ void ntt_tile_rounds(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (!INVERSE) {
-        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, true>(a, bx, by, lds);
-        else NttRounds<LOGM, STRIDED, INVERSE, CC>::template fwd<0, 0, false>(a, bx, by, lds);
+        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH>::template fwd<0, 0, true>(a, bx, by, lds);
+        else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH>::template fwd<0, 0, false>(a, bx, by, lds);
     } else {
-        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC>::template inv<NttSched<LOGM>::R - 1, LOGM, true>(a, bx, by, lds);
-        else NttRounds<LOGM, STRIDED, INVERSE, CC>::template inv<NttSched<LOGM>::R - 1, LOGM, false>(a, bx, by, lds);
+        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, true>(a, bx, by, lds);
+        else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, false>(a, bx, by, lds);
     }
 }
 
 // one pass of one tile: load phase, register rounds through LDS, store phase
-template <int LOGM, bool STRIDED, bool INVERSE, bool FULL>
+template <int LOGM, bool STRIDED, bool INVERSE, bool FULL, int T = NTT_THREADS, int SCH = T, int TL = NttTile::LOG>
 static __device__ __forceinline__ void ntt_pass_tile(const NttArgs &a, int bx, int by, u64 *lds)
 {
-    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? NttTile::LOG - LOGM : -1;
-    ntt_body_load<STRIDED, INVERSE, CM, CC>(a, bx, by, threadIdx.x, lds);
+    constexpr int CM = FULL ? LOGM : -1, CC = FULL ? TL - LOGM : -1;
+    ntt_body_load<STRIDED, INVERSE, CM, CC, T>(a, bx, by, threadIdx.x, lds);
     __syncthreads();
-    ntt_tile_rounds<LOGM, STRIDED, INVERSE, CC>(a, bx, by, lds);
-    ntt_body_store<STRIDED, INVERSE, CM, CC>(a, bx, by, threadIdx.x, lds);
+    ntt_tile_rounds<LOGM, STRIDED, INVERSE, CC, T, SCH>(a, bx, by, lds);
+    ntt_body_store<STRIDED, INVERSE, CM, CC, T>(a, bx, by, threadIdx.x, lds);
 }
 
 // FULL: the tile is 2^LOGM points x 2^(12 - LOGM) columns (every launch with N >= 4096) -> geometry folds into constants
@@ -168,6 +169,17 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream s)
     }
 }
 
+// one pass only: `second` = false runs the first pass of the transform (its load ops), true the second (its store ops)
+void k_ntt_pass(const NttArgs &a, bool inverse, bool second, rt_stream s)
+{
+    if (a.count <= 0) return;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    hipStream_t st = (hipStream_t)s;
+    if (!inverse) { if (!second) launch_pass<true, false>(a, n1, n2, st); else launch_pass<false, false>(a, n2, n1, st); }
+    else { if (!second) launch_pass<false, true>(a, n2, n1, st); else launch_pass<true, true>(a, n1, n2, st); }
+}
+
 template <bool STRIDED, bool INVERSE>
 static void launch_pass2(NttArgs a1, NttArgs a2, int logm, int other, hipStream_t st)
 {
@@ -199,6 +211,15 @@ void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s)
     launch_pass2<true, false>(a1, a2, n1, n2, (hipStream_t)s);
     launch_pass2<false, false>(a1, a2, n2, n1, (hipStream_t)s);
 }
+// first (strided) pass of the forward transforms of two batches in one grid
+void k_ntt2_fwd_first(const NttArgs &a1, const NttArgs &a2, rt_stream s)
+{
+    if (a1.count <= 0) { k_ntt_pass(a2, false, false, s); return; }
+    if (a2.count <= 0) { k_ntt_pass(a1, false, false, s); return; }
+    int n1, n2;
+    ntt_split(a1.logn, n1, n2);
+    launch_pass2<true, false>(a1, a2, n1, n2, (hipStream_t)s);
+}
 // inverse transforms of two batches where the store epilogue of the SECOND may read results of the first: the row passes
 // (no such dependency yet) share one grid, the strided passes run one after the other
 void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s)
@@ -210,6 +231,76 @@ void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s)
     launch_pass2<false, true>(a1, a2, n2, n1, st);
     launch_pass<true, true>(a1, n1, n2, st);
     launch_pass<true, true>(a2, n1, n2, st);
+}
+
+// ---------------------------------------------------------------- fused key-switch row kernel
+// 8 points per lane: the 2 x 8 lazy sums of a lane live in registers beside a radix-8 round inside the 128-VGPR budget of
+// 4 waves per SIMD.  Measured alternatives (round 2, config 2, transcipherings/s): 4096-point tiles on 256 lanes x 16 points
+// need 173+ VGPRs -- 200 at 3 waves per SIMD (spills), 237 at 2 waves per SIMD; 4096-point tiles on 512 lanes: 238.
+template <int LOGM>
+__global__ void __launch_bounds__(KSROW_THREADS, KSROW_THREADS / 64) ks_row_kernel(NttArgs a, KsRowArgs x, NttArgs c0)
+{
+    __shared__ u64 lds[KSROW_LDS];
+    constexpr int CC = KSROW_TILE_LOG - LOGM, T = KSROW_THREADS, SCH = KSROW_SCHED;
+    // the first c0.count polynomials of the grid are an ordinary forward row pass (the c0 branch of the previous rotation
+    // step with its mod-down epilogue): memory-bound tiles that run beside the arithmetic-bound key-switch tiles
+    const unsigned nc0 = (unsigned)c0.count << a.tiles_log;
+    if (blockIdx.x < nc0) {
+        ntt_pass_tile<LOGM, false, false, true, T, SCH, KSROW_TILE_LOG>(c0, (int)(blockIdx.x & ((1u << a.tiles_log) - 1)), (int)(blockIdx.x >> a.tiles_log), lds);
+        return;
+    }
+    const unsigned bid = blockIdx.x - nc0;
+    const int bx = (int)(bid & ((1u << a.tiles_log) - 1)), y = (int)(bid >> a.tiles_log);
+    const int b = y / x.K, J = y % x.K, tid = threadIdx.x;
+    const size_t n = (size_t)1 << a.logn;
+    u64 acc0[2 * KSROW_NP], acc1[2 * KSROW_NP];
+#pragma unroll
+    for (int k = 0; k < 2 * KSROW_NP; k++) { acc0[k] = 0; acc1[k] = 0; }
+    for (int I = 0; I < x.L; I++) {
+        const int by = (b * x.L + I) * x.K + J;
+        ntt_body_load<false, false, LOGM, CC, T>(a, bx, by, tid, lds);
+        __syncthreads();
+        ntt_tile_rounds<LOGM, false, false, CC, T, SCH>(a, bx, by, lds);
+        ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, tid, lds, acc0, acc1);
+        __syncthreads();
+    }
+    if (J < x.L) {
+        ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
+        ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
+        __syncthreads();
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
+        ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U1 + ((size_t)b * x.L + J) * n);
+    } else {
+        ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
+        __syncthreads();
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
+        ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 0) * n);
+        __syncthreads();
+        ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
+        __syncthreads();
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
+        ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 1) * n);
+    }
+}
+bool k_ks_row_supported(int logn) { return logn >= 12; }
+void k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s)
+{
+    NttArgs a = a0, c0;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    a.logm = n2;
+    a.logc = KSROW_TILE_LOG - n2;
+    a.tiles_log = n1 - a.logc;
+    if (c0_row) { c0 = *c0_row; c0.logm = a.logm; c0.logc = a.logc; c0.tiles_log = a.tiles_log; }
+    else { memset(&c0, 0, sizeof(c0)); }
+    dim3 grid((unsigned)(((size_t)x.B * x.K + c0.count) << a.tiles_log));
+    hipStream_t st = (hipStream_t)s;
+    switch (n2) {
+    case 6: hipLaunchKernelGGL((ks_row_kernel<6>), grid, dim3(KSROW_THREADS), 0, st, a, x, c0); break;
+    case 7: hipLaunchKernelGGL((ks_row_kernel<7>), grid, dim3(KSROW_THREADS), 0, st, a, x, c0); break;
+    case 8: hipLaunchKernelGGL((ks_row_kernel<8>), grid, dim3(KSROW_THREADS), 0, st, a, x, c0); break;
+    default: snprintf(g_rt_err, sizeof(g_rt_err), "ks_row: unsupported row pass size 2^%d", n2); break;
+    }
 }
 
 // ---------------------------------------------------------------- element-wise family

@@ -31,6 +31,13 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream s);  // runs both passes; a
 void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s);
 // inverse transforms of two batches; the store epilogue of the second may read the results of the first (row passes share a grid)
 void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s);
+// one pass of a transform: second = false -> first pass (load ops), true -> second pass (store ops)
+void k_ntt_pass(const NttArgs &a, bool inverse, bool second, rt_stream s);
+void k_ntt2_fwd_first(const NttArgs &a1, const NttArgs &a2, rt_stream s);  // first forward pass of two batches in one grid
+// fused key-switch row kernel (full 4096-point tiles only: N >= 4096); a = the digit transforms' NttArgs (dst = T);
+// c0_row (optional) = a forward transform whose second (row) pass runs in the same grid
+bool k_ks_row_supported(int logn);
+void k_ks_row(const NttArgs &a, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s);
 void k_elt(const EltArgs &a, int op, rt_stream s);
 void k_galois(const GaloisArgs &a, rt_stream s);
 void k_perm(const PermArgs &a, rt_stream s);

@@ -55,6 +55,14 @@ HD u64 reduce64(u64 x, const ModDev &m)
     u64 r = x - mulhi64(x, m.r_hi) * m.q;
     return r >= m.q ? r - m.q : r;
 }
+// floor(w * 2^64 / q) for w < q: the Shoup quotient of a fixed multiplicand
+HD u64 shoup_quotient(u64 w, const ModDev &m)
+{
+    u64 quo = barrett_quo(0, w, m.r_lo, m.r_hi);  // at most 3 below the true quotient
+    u64 rem = 0 - quo * m.q;                      // w * 2^64 - quo * q < 4q, exact in 64 bits
+    while (rem >= m.q) { rem -= m.q; quo++; }
+    return quo;
+}
 // 128-bit lazy accumulator
 struct Acc128 {
     u64 lo, hi;

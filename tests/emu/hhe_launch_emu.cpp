@@ -28,34 +28,34 @@ void rt_event_destroy(void *) {}
 int rt_event_record(void *, rt_stream) { return 0; }
 int rt_stream_wait_event(rt_stream, void *) { return 0; }
 
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int S0, bool LAZY8 = false>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int S0, bool LAZY8 = false>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
 {
-    if constexpr (I < NttSched<LOGM>::R) {
-        constexpr int RHO = NttSched<LOGM>::rho(I);
-        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC>(a, bx, by, t, lds);
-        rounds_fwd<LOGM, STRIDED, INVERSE, CC, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
+    if constexpr (I < NttSched<LOGM, SCH>::R) {
+        constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
+        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T>(a, bx, by, t, lds);
+        rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
     }
 }
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int I, int SEND, bool LAZY8 = false>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int SEND, bool LAZY8 = false>
 static void rounds_inv(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (I >= 0) {
-        constexpr int RHO = NttSched<LOGM>::rho(I);
-        for (int t = 0; t < NTT_THREADS; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC>(a, bx, by, t, lds);
-        rounds_inv<LOGM, STRIDED, INVERSE, CC, I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
+        constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
+        for (int t = 0; t < T; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC, T>(a, bx, by, t, lds);
+        rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
     }
 }
 // the register rounds of one pass over a staged tile (a barrier after each round = the end of the thread loop)
-template <int LOGM, bool STRIDED, bool INVERSE, int CC>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int SCH = T>
 static void tile_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (!INVERSE) {
-        if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, 0, 0, true>(a, bx, by, lds);
-        else rounds_fwd<LOGM, STRIDED, INVERSE, CC, 0, 0, false>(a, bx, by, lds);
+        if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true>(a, bx, by, lds);
+        else rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, false>(a, bx, by, lds);
     }
-    else if (a.lazy8) rounds_inv<LOGM, STRIDED, INVERSE, CC, NttSched<LOGM>::R - 1, LOGM, true>(a, bx, by, lds);
-    else rounds_inv<LOGM, STRIDED, INVERSE, CC, NttSched<LOGM>::R - 1, LOGM, false>(a, bx, by, lds);
+    else if (a.lazy8) rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, NttSched<LOGM, SCH>::R - 1, LOGM, true>(a, bx, by, lds);
+    else rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, NttSched<LOGM, SCH>::R - 1, LOGM, false>(a, bx, by, lds);
 }
 template <int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 static void pass_emu(const NttArgs &a, int gx, int gy)
@@ -95,6 +95,78 @@ void k_ntt(const NttArgs &a, bool inverse, rt_stream)
     ntt_split(a.logn, n1, n2);
     if (!inverse) { launch_pass<true, false>(a, n1, n2); launch_pass<false, false>(a, n2, n1); }
     else { launch_pass<false, true>(a, n2, n1); launch_pass<true, true>(a, n1, n2); }
+}
+void k_ntt_pass(const NttArgs &a, bool inverse, bool second, rt_stream)
+{
+    if (a.count <= 0) return;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    if (!inverse) { if (!second) launch_pass<true, false>(a, n1, n2); else launch_pass<false, false>(a, n2, n1); }
+    else { if (!second) launch_pass<false, true>(a, n2, n1); else launch_pass<true, true>(a, n1, n2); }
+}
+void k_ntt2_fwd_first(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt_pass(a1, false, false, s); k_ntt_pass(a2, false, false, s); }
+bool k_ks_row_supported(int logn) { return logn >= 12; }
+template <int LOGM>
+static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, int gx, int gy)
+{
+    constexpr int CC = KSROW_TILE_LOG - LOGM, T = KSROW_THREADS, SCH = KSROW_SCHED;
+    const size_t n = (size_t)1 << a.logn;
+#pragma omp parallel
+    {
+        std::vector<u64> lds(KSROW_LDS);
+        std::vector<u64> acc0((size_t)T * 2 * KSROW_NP), acc1((size_t)T * 2 * KSROW_NP);
+        auto A0 = [&](int t) { return &acc0[(size_t)t * 2 * KSROW_NP]; };
+        auto A1 = [&](int t) { return &acc1[(size_t)t * 2 * KSROW_NP]; };
+#pragma omp for collapse(2)
+        for (int by = 0; by < c0.count; by++)  // the c0-branch tiles of the grid: a plain forward row pass at this kernel's geometry
+            for (int bx = 0; bx < gx; bx++) {
+                for (int t = 0; t < T; t++) ntt_body_load<false, false, LOGM, CC, T>(c0, bx, by, t, lds.data());
+                tile_rounds_emu<LOGM, false, false, CC, T, SCH>(c0, bx, by, lds.data());
+                for (int t = 0; t < T; t++) ntt_body_store<false, false, LOGM, CC, T>(c0, bx, by, t, lds.data());
+            }
+#pragma omp for collapse(2)
+        for (int y = 0; y < gy; y++)
+            for (int bx = 0; bx < gx; bx++) {
+                const int b = y / x.K, J = y % x.K;
+                std::fill(acc0.begin(), acc0.end(), 0);
+                std::fill(acc1.begin(), acc1.end(), 0);
+                for (int I = 0; I < x.L; I++) {
+                    const int by = (b * x.L + I) * x.K + J;
+                    for (int t = 0; t < T; t++) ntt_body_load<false, false, LOGM, CC, T>(a, bx, by, t, lds.data());
+                    tile_rounds_emu<LOGM, false, false, CC, T, SCH>(a, bx, by, lds.data());
+                    for (int t = 0; t < T; t++) ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, t, lds.data(), A0(t), A1(t));
+                }
+                auto inverse_to = [&](std::vector<u64> &acc, u64 *out) {
+                    for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), &acc[(size_t)t * 2 * KSROW_NP], nullptr);
+                    tile_rounds_emu<LOGM, false, true, CC, T, SCH>(a, bx, J, lds.data());
+                    for (int t = 0; t < T; t++) ks_row_store_phase<LOGM, CC>(a, bx, J, t, lds.data(), out);
+                };
+                if (J < x.L) {
+                    for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), A0(t), x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
+                    inverse_to(acc1, x.U1 + ((size_t)b * x.L + J) * n);
+                } else {
+                    inverse_to(acc0, x.Usp + ((size_t)b * 2 + 0) * n);
+                    inverse_to(acc1, x.Usp + ((size_t)b * 2 + 1) * n);
+                }
+            }
+    }
+}
+void k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_stream)
+{
+    NttArgs a = a0, c0;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    a.logm = n2;
+    a.logc = KSROW_TILE_LOG - n2;
+    if (c0_row) { c0 = *c0_row; c0.logm = a.logm; c0.logc = a.logc; }
+    else memset(&c0, 0, sizeof(c0));
+    const int gx = 1 << (n1 - a.logc), gy = x.B * x.K;
+    switch (n2) {
+    case 6: ks_row_emu<6>(a, x, c0, gx, gy); break;
+    case 7: ks_row_emu<7>(a, x, c0, gx, gy); break;
+    case 8: ks_row_emu<8>(a, x, c0, gx, gy); break;
+    default: abort();
+    }
 }
 void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, false, s); k_ntt(a2, false, s); }
 void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, true, s); k_ntt(a2, true, s); }

@@ -302,3 +302,29 @@ def test_config4_two_layer_chain(orc, api, emu_lib, mem):
     X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
     S.load_keys(X)
     pc.check_two_layer_chain(X, S, mem)
+
+
+@pytest.mark.parametrize("logn,bits", [(12, [50, 50, 50]), (13, [40] * 6)])
+def test_fused_row_kernel_full_tiles(orc, api, emu_lib, mem, logn, bits):
+    """N >= 4096: the matmul loop runs ks_row_kernel (row pass of the digit transforms + key inner product with Shoup key
+    products + inverse row pass in one kernel; the c0 branch rides in its grid).  Same words as the oracle; L = 5 also
+    exercises the fold of the lazy sums after the fourth digit."""
+    S = Setup(orc, logn, bits)
+    pt = [(13 * i + 7) % 256 for i in range(100)]
+    cw, ncw = S.sym_blocks(orc, pt)
+    ref = S.O.transcipher_block(S.enc_key, S.rk, S.gk, cw[0, :ncw[0]], 3)
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    out = mem.empty((2,) + S.O.ct_shape)
+    X.transcipher(mem.to_dev(S.enc_key), np.concatenate([cw, cw]), [ncw[0], ncw[0]], [3, 3], out)
+    res = mem.to_host(out)
+    assert (res[0] == ref).all() and (res[1] == ref).all()
+    # the literal op-by-op schedule (HHE_MATMUL=0 at context creation) gives the same words
+    os.environ["HHE_MATMUL"] = "0"
+    try:
+        X0 = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    finally:
+        del os.environ["HHE_MATMUL"]
+    S.load_keys(X0)
+    X0.transcipher(mem.to_dev(S.enc_key), cw, [ncw[0]], [3], out)
+    assert (mem.to_host(out)[0] == ref).all()
