@@ -54,6 +54,16 @@ int hhe_ctx_set_stream(hhe_ctx *c, void *hip_stream);
 /* size per-batch workspaces for up to max_batch ciphertexts (allocated once, reused) */
 int hhe_ctx_reserve(hhe_ctx *c, size_t max_batch);
 int hhe_ctx_sync(hhe_ctx *c);
+/* Thread safety: every entry point that takes a context serialises on a lock inside it (the reference's gRPC handlers call
+ * the cipher concurrently, src/examples/CSP/CSPRPC.cpp:201-203); different contexts are independent.  hhe_ctx_destroy must
+ * not race with other calls on the same context. */
+/* Timing instrumentation of the dominant kernel (no reference counterpart; the reference brackets phases with std::chrono,
+ * src/examples/hhe_pktnn_examples.cpp:73-76): while enabled, every launch of the fused key-switch row kernel is bracketed
+ * by timed HIP events on the stream it is launched on.  hhe_ctx_profile_read waits for the work, returns the number of
+ * launches, the sum of their durations and the ciphertexts they covered, and resets the counters.  Results of the ops are
+ * unaffected.  kernel_name (optional, name_cap bytes) receives the kernel's name as rocprofv3 prints it. */
+int hhe_ctx_profile(hhe_ctx *c, int enable);
+int hhe_ctx_profile_read(hhe_ctx *c, char *kernel_name, size_t name_cap, uint64_t *launches, double *total_ms, uint64_t *items);
 /* derived parameters, for cross-checking against SEAL's context: what in
  * {"root" i<K, "bsk" i<=L (B_0.., m_sk), "gamma", "galois_elt" i=step, "fc_fallbacks"} */
 uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i);

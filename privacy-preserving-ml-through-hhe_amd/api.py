@@ -33,6 +33,7 @@ _SYMBOLS = [
     "hhe_rotate_rows", "hhe_rotate_columns", "hhe_multiply", "hhe_relinearize",
     "hhe_pasta3_transcipher", "hhe_pasta3_clear_block_cache", "hhe_mask", "hhe_flatten", "hhe_fc_row", "hhe_decompose",
     "hhe_pasta3_block_randomness", "hhe_pasta3_plain_keystream", "hhe_pasta3_plain_crypt", "hhe_decrypt",
+    "hhe_ctx_profile", "hhe_ctx_profile_read",
 ]
 
 
@@ -123,6 +124,17 @@ class Context:
 
     def sync(self):
         self._chk(self.lib.hhe_ctx_sync(self.h))
+
+    def profile(self, enable=True):
+        """bracket every launch of the fused key-switch row kernel with timed HIP events on its stream"""
+        self._chk(self.lib.hhe_ctx_profile(self.h, C.c_int(1 if enable else 0)))
+
+    def profile_read(self):
+        """(kernel name as rocprofv3 prints it, launches, total ms, ciphertexts covered) since the last read"""
+        name = C.create_string_buffer(128)
+        n, items, ms = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+        self._chk(self.lib.hhe_ctx_profile_read(self.h, name, C.c_size_t(128), C.byref(n), C.byref(ms), C.byref(items)))
+        return name.value.decode(), int(n.value), float(ms.value), int(items.value)
 
     def set_relin_key(self, ksk):
         ksk = np.ascontiguousarray(ksk, dtype=np.uint64)

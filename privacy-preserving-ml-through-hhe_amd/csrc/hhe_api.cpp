@@ -20,6 +20,19 @@ int need(hhe_ctx *c, size_t B)
     return lane_reserve(c, c->lanes[0], B);
 }
 
+// host staging of a lane: wait for the previous staged copy before the buffers are overwritten; mark the new one
+void stage_begin(Lane &ln)
+{
+    if (ln.stage_pending && ln.ev_stage) rt_event_sync(ln.ev_stage);
+    ln.stage_pending = false;
+}
+void stage_end(Lane &ln)
+{
+    if (!ln.ev_stage) ln.ev_stage = rt_event_create();
+    if (ln.ev_stage && !rt_event_record(ln.ev_stage, ln.stream)) ln.stage_pending = true;
+    else rt_sync(ln.stream);
+}
+
 NttArgs ntt_args(const hhe_ctx *c, const u64 *src, u64 *dst, size_t count, int mod_base, int mod_cycle)
 {
     NttArgs a;
@@ -358,6 +371,26 @@ int matmul_diagonal(hhe_ctx *c, int layer, const u64 *const *d_diag_ptrs, size_t
     return HHE_OK;
 }
 
+// hhe_ctx_profile: one timed event pair around a launch on the lane's stream (the stream the kernel runs on)
+struct ProfScope {
+    Lane *ln = nullptr;
+    void *e1 = nullptr;
+    ProfScope(hhe_ctx *c, Lane &lane, size_t items)
+    {
+        if (!c->profile) return;
+        if (lane.prof_used == lane.prof_ev.size()) {
+            void *a = rt_event_create_timed(), *b = rt_event_create_timed();
+            if (!a || !b) { rt_event_destroy(a); rt_event_destroy(b); return; }
+            lane.prof_ev.emplace_back(a, b);
+        }
+        auto &pr = lane.prof_ev[lane.prof_used++];
+        ln = &lane; e1 = pr.second;
+        c->prof_items += items;
+        rt_event_record(pr.first, lane.stream);
+    }
+    ~ProfScope() { if (ln) rt_event_record(e1, ln->stream); }
+};
+
 // Shoup quotients floor(key * 2^64 / q_J) of a key-switch key ([L][2][K][N], as the key), built on first use by the
 // fused row kernel and cached per Galois element
 int ensure_key_shoup(hhe_ctx *c, u32 elt, const u64 *key, const u64 **out)
@@ -438,7 +471,10 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             memset(&x, 0, sizeof(x));
             x.key = key; x.key_s = key_s; x.S = c->w->ws_S + (size_t)(i & 1) * K * n; x.U1 = scr; x.Usp = r; x.B = (int)B; x.L = L; x.K = K;
             x.acc = accp1; x.mul_ptrs = d_pdiag_ptrs; x.mul_shift = shift;
-            k_ks_row(a, x, k5_pending ? &k5 : nullptr, c->w->stream);
+            {
+                ProfScope prof(c, *c->w, B);
+                k_ks_row(a, x, k5_pending ? &k5 : nullptr, c->w->stream);
+            }
             k5_pending = false;
             // second (strided) inverse passes: r_k = INTT(S_k[special]) + floor(q_sp/2); c1 of the next state through the
             // mod-down epilogue and the Galois map
@@ -511,36 +547,42 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
 // ====================================================================== C ABI
 extern "C" int hhe_ntt(hhe_ctx *c, uint64_t *polys, size_t count, int mod_base, int mod_cycle, int inverse)
 {
+    HHE_LOCK(c);
     if (!c || !polys || mod_cycle < 1 || mod_base < 0 || mod_base + mod_cycle > c->nmod) return fail(HHE_ERR_INVALID, "hhe_ntt: bad arguments");
     op_ntt(c, polys, count, mod_base, mod_cycle, inverse != 0);
     return HHE_OK;
 }
 extern "C" int hhe_encode(hhe_ctx *c, const uint64_t *vals, size_t B, size_t count, uint64_t *plain)
 {
+    HHE_LOCK(c);
     if (!c || !vals || !plain || count > c->n) return fail(HHE_ERR_INVALID, "hhe_encode: bad arguments");
     op_encode(c, vals, B, (int)count, (int)count, -1, plain);
     return HHE_OK;
 }
 extern "C" int hhe_add(hhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t B, int size)
 {
+    HHE_LOCK(c);
     if (!c || !a || !b || !out) return fail(HHE_ERR_INVALID, "hhe_add: bad arguments");
     op_add(c, a, b, out, B, size);
     return HHE_OK;
 }
 extern "C" int hhe_negate(hhe_ctx *c, const uint64_t *a, uint64_t *out, size_t B, int size)
 {
+    HHE_LOCK(c);
     if (!c || !a || !out) return fail(HHE_ERR_INVALID, "hhe_negate: bad arguments");
     op_elt(c, ELT_NEG, a, nullptr, out, B * size * c->L, 0, c->L);
     return HHE_OK;
 }
 extern "C" int hhe_add_plain(hhe_ctx *c, const uint64_t *ct, const uint64_t *plain, int bcast, int subtract, uint64_t *out, size_t B)
 {
+    HHE_LOCK(c);
     if (!c || !ct || !plain || !out) return fail(HHE_ERR_INVALID, "hhe_add_plain: bad arguments");
     op_add_plain(c, ct, plain, nullptr, 0, bcast != 0, subtract != 0, false, out, B);
     return HHE_OK;
 }
 extern "C" int hhe_multiply_plain(hhe_ctx *c, const uint64_t *ct, const uint64_t *plain, int bcast, uint64_t *out, size_t B)
 {
+    HHE_LOCK(c);
     if (!c || !ct || !plain || !out) return fail(HHE_ERR_INVALID, "hhe_multiply_plain: bad arguments");
     int rc = need(c, B);
     if (rc) return rc;
@@ -549,42 +591,44 @@ extern "C" int hhe_multiply_plain(hhe_ctx *c, const uint64_t *ct, const uint64_t
     op_lift_ntt(c, plain, P, D);
     if (bcast) op_multiply_plain_ntt(c, ct, D, nullptr, 0, out, B);
     else {
+        // per-item multiplier: items laid [B][L][N]; the pointer form of the fused store reads the lane's pointer table
+        Lane &ln = *c->w;
+        stage_begin(ln);
+        ln.h_ptrs.assign(B, nullptr);
+        for (size_t b = 0; b < B; ++b) ln.h_ptrs[b] = D + b * c->L * c->n;
+        rt_h2d(ln.d_ptrs, ln.h_ptrs.data(), B * sizeof(u64 *), ln.stream);
+        stage_end(ln);
         NttArgs a = ntt_args(c, ct, out, B * 2 * c->L, 0, c->L);
-        a.store_op = STORE_MUL;
-        // per-item multiplier: items laid [B][L][N]; reuse the pointer form with a flat table
-        std::vector<const u64 *> ptrs(B);
-        for (size_t b = 0; b < B; ++b) ptrs[b] = D + b * c->L * c->n;
-        const u64 **dp = (const u64 **)rt_malloc(B * sizeof(u64 *));
-        if (!dp) return dev_fail("hhe_multiply_plain");
-        rt_h2d(dp, ptrs.data(), B * sizeof(u64 *), c->w->stream);
-        a.mul_ptrs = dp; a.mul_cycle = c->L; a.mul_item_polys = 2 * c->L;
-        k_ntt(a, false, c->w->stream);
+        a.store_op = STORE_MUL; a.mul_ptrs = ln.d_ptrs; a.mul_cycle = c->L; a.mul_item_polys = 2 * c->L;
+        k_ntt(a, false, ln.stream);
         op_ntt(c, out, B * 2 * c->L, 0, c->L, true);
-        rt_sync(c->w->stream);
-        rt_free(dp);
     }
     return HHE_OK;
 }
 extern "C" int hhe_apply_galois(hhe_ctx *c, const uint64_t *ct, uint32_t elt, uint64_t *out, size_t B)
 {
+    HHE_LOCK(c);
     int rc = need(c, B);
     if (rc) return rc;
     return op_apply_galois(c, ct, elt, out, B);
 }
 extern "C" int hhe_rotate_rows(hhe_ctx *c, const uint64_t *ct, int step, uint64_t *out, size_t B)
 {
+    HHE_LOCK(c);
     int rc = need(c, B);
     if (rc) return rc;
     return op_rotate_rows(c, ct, step, out, B);
 }
 extern "C" int hhe_rotate_columns(hhe_ctx *c, const uint64_t *ct, uint64_t *out, size_t B)
 {
+    HHE_LOCK(c);
     int rc = need(c, B);
     if (rc) return rc;
     return op_apply_galois(c, ct, (u32)(2 * c->n - 1), out, B);
 }
 extern "C" int hhe_multiply(hhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out3, size_t B)
 {
+    HHE_LOCK(c);
     int rc = need(c, B);
     if (rc) return rc;
     op_multiply(c, a, b, out3, B);
@@ -592,6 +636,7 @@ extern "C" int hhe_multiply(hhe_ctx *c, const uint64_t *a, const uint64_t *b, ui
 }
 extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, size_t B)
 {
+    HHE_LOCK(c);
     int rc = need(c, B);
     if (rc) return rc;
     return op_relinearize(c, a3, out, B);
@@ -644,6 +689,7 @@ static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d
 extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *cw, const uint32_t *ncw,
                                       const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
 {
+    HHE_LOCK(c);
     if (!c || !enc_key || !cw || !ncw || !block_index || !out || B == 0) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: null argument or empty batch");
     const size_t n = c->n, half = n / 2;
     // pasta_3_seal.cpp:376-377
@@ -715,36 +761,39 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
 
 extern "C" int hhe_mask(hhe_ctx *c, const uint64_t *ct, const uint64_t *mask_vals, size_t count, uint64_t *out, size_t B)
 {
+    HHE_LOCK(c);
     if (!c || !ct || !mask_vals || !out || count > c->n) return fail(HHE_ERR_INVALID, "hhe_mask: bad arguments");
     int rc = need(c, B);
     if (rc) return rc;
-    u64 *dv = (u64 *)rt_malloc(count * 8);
-    if (!dv) return dev_fail("hhe_mask");
-    rt_h2d(dv, mask_vals, count * 8, c->w->stream);
-    op_encode(c, dv, 1, (int)count, (int)count, -1, c->w->ws_plain);
-    u64 *D = c->w->ws_ct3;
-    op_lift_ntt(c, c->w->ws_plain, 1, D);
+    // D = lifted NTT form of the mask plaintext in ws_ct3 [0, L*N); the mask values are staged behind it
+    Lane &ln = *c->w;
+    u64 *D = ln.ws_ct3, *dv = ln.ws_ct3 + (size_t)c->L * c->n;
+    stage_begin(ln);
+    ln.h_stage.assign(mask_vals, mask_vals + count);
+    rt_h2d(dv, ln.h_stage.data(), count * 8, ln.stream);
+    stage_end(ln);
+    op_encode(c, dv, 1, (int)count, (int)count, -1, ln.ws_plain);
+    op_lift_ntt(c, ln.ws_plain, 1, D);
     op_multiply_plain_ntt(c, ct, D, nullptr, 0, out, B);
-    if (rt_sync(c->w->stream)) rc = dev_fail("hhe_mask");
-    rt_free(dv);
-    return rc;
+    return HHE_OK;
 }
 
 extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, uint64_t *out, size_t S)
 {
+    HHE_LOCK(c);
     if (!c || !blocks || !out || nblocks == 0) return fail(HHE_ERR_INVALID, "hhe_flatten: bad arguments");
     int rc = need(c, S);
     if (rc) return rc;
     const size_t ctw = c->ct_words();
-    // gather block i of every sample into a contiguous batch, rotate by -128*i, accumulate
-    EltArgs g;
-    auto gather = [&](size_t i, u64 *dst) {
-        for (size_t s = 0; s < S; ++s) rt_d2d(dst + s * ctw, blocks + (s * nblocks + i) * ctw, ctw * 8, c->w->stream);
-    };
-    (void)g;
-    gather(0, out);
+    // gather block i of every sample into a contiguous batch (one strided copy kernel), rotate by -128*i, accumulate
+    CopyItemsArgs g;
+    memset(&g, 0, sizeof(g));
+    g.src = blocks; g.words = ctw; g.count = S; g.src_stride = nblocks; g.dst_stride = 1;
+    g.dst = out;
+    k_copy_items(g, c->w->stream);
     for (size_t i = 1; i < nblocks; ++i) {
-        gather(i, c->w->ws_ct[0]);
+        g.dst = c->w->ws_ct[0]; g.src_off = i;
+        k_copy_items(g, c->w->stream);
         if ((rc = op_rotate_rows(c, c->w->ws_ct[0], -(int)(i * PASTA_T), c->w->ws_ct[1], S))) return rc;
         op_add(c, out, c->w->ws_ct[1], out, S, 2);
     }
@@ -756,6 +805,7 @@ extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, u
 extern "C" int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *records, size_t S, size_t nwords,
                              int mask_last, uint64_t *out)
 {
+    HHE_LOCK(c);
     if (!c || !enc_key || !records || !out || S == 0 || nwords == 0) return fail(HHE_ERR_INVALID, "hhe_decompose: bad arguments");
     const size_t nb = (nwords + PASTA_T - 1) / PASTA_T, rem = nwords % PASTA_T, ctw = c->ct_words();
     if (nb * PASTA_T > c->n / 2) return fail(HHE_ERR_INVALID, "hhe_decompose: record does not fit one batching row");
@@ -768,26 +818,32 @@ extern "C" int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key, const uint64_t
             ncw[s * nb + b] = (uint32_t)(hi - lo);
             bidx[s * nb + b] = b;
         }
-    u64 *blocks = (u64 *)rt_malloc(S * nb * ctw * 8);
-    if (!blocks) return dev_fail("hhe_decompose");
+    if (c->blocks_cap < S * nb * ctw) {  // grow-only scratch for the decompositions of all blocks
+        sync_ctx(c);
+        rt_free(c->d_blocks);
+        c->blocks_cap = 0;
+        if (!(c->d_blocks = (u64 *)rt_malloc(S * nb * ctw * 8))) return dev_fail("hhe_decompose");
+        c->blocks_cap = S * nb * ctw;
+    }
+    u64 *blocks = c->d_blocks;
     int rc = hhe_pasta3_transcipher(c, enc_key, cw.data(), ncw.data(), bidx.data(), S * nb, 0, blocks);
     if (!rc && mask_last && rem) {
         // hhe_pktnn_examples.cpp:620-625: ones on the first `rem` slots (CSP.cpp:264-269 intends the same)
-        u64 *last = (u64 *)rt_malloc(S * ctw * 8);
-        if (!last) rc = dev_fail("hhe_decompose");
-        else {
+        if (!(rc = need(c, S))) {
+            u64 *last = c->lanes[0].ws_ct[2];
             rt_stream st = c->lanes[0].stream;
-            for (size_t s = 0; s < S; ++s) rt_d2d(last + s * ctw, blocks + (s * nb + nb - 1) * ctw, ctw * 8, st);
+            CopyItemsArgs g;
+            memset(&g, 0, sizeof(g));
+            g.src = blocks; g.dst = last; g.words = ctw; g.count = S; g.src_stride = nb; g.src_off = nb - 1; g.dst_stride = 1;
+            k_copy_items(g, st);
             std::vector<u64> ones(rem, 1);
             rc = hhe_mask(c, last, ones.data(), rem, last, S);
-            for (size_t s = 0; s < S && !rc; ++s) rt_d2d(blocks + (s * nb + nb - 1) * ctw, last + s * ctw, ctw * 8, st);
-            rt_sync(st);
-            rt_free(last);
+            g.src = last; g.dst = blocks; g.src_stride = 1; g.src_off = 0; g.dst_stride = nb; g.dst_off = nb - 1;
+            if (!rc) k_copy_items(g, st);
         }
     }
     if (!rc) rc = hhe_flatten(c, blocks, nb, out, S);
     if (!rc && rt_sync(c->lanes[0].stream)) rc = dev_fail("hhe_decompose");
-    rt_free(blocks);
     return rc;
 }
 
@@ -969,6 +1025,7 @@ static int fc_row_chunk(hhe_ctx *c, Lane &ln, bool shared, const uint64_t *vi, c
 extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
                           int default_galois_only, uint64_t *out, size_t B)
 {
+    HHE_LOCK(c);
     if (!c || !vi || !w || !out || W == 0 || B == 0 || n_inputs == 0 || n_inputs > c->n / 2 || relin_slot < 0 || relin_slot >= HHE_RELIN_SLOTS)
         return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
     if (!c->d_rk_slot[relin_slot]) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
@@ -984,7 +1041,14 @@ extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, siz
     const bool shared = c->fc_shared != 0;
     u32 *flags = nullptr;
     if (shared) {
-        if (!(flags = (u32 *)rt_malloc(nch * 4))) return dev_fail("hhe_fc_row");
+        if (c->flags_cap < nch) {  // grow-only per-chunk flags
+            sync_ctx(c);
+            rt_free(c->d_flags);
+            c->flags_cap = 0;
+            if (!(c->d_flags = (u32 *)rt_malloc(nch * 4))) return dev_fail("hhe_fc_row");
+            c->flags_cap = nch;
+        }
+        flags = c->d_flags;
         rt_memset(flags, 0, nch * 4, main.stream);
     }
     int rc = HHE_OK;
@@ -1016,7 +1080,6 @@ extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, siz
             }
     }
     if (rt_sync(main.stream) && !rc) rc = dev_fail("hhe_fc_row");
-    rt_free(flags);
     return rc;
 }
 

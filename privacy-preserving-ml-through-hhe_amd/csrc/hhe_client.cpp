@@ -42,6 +42,7 @@ int keystream_into(hhe_ctx *c, const uint64_t *key, uint64_t first_block, size_t
 
 extern "C" int hhe_pasta3_plain_keystream(hhe_ctx *c, const uint64_t *key, uint64_t first_block, size_t nblocks, uint64_t *ks)
 {
+    HHE_LOCK(c);
     if (!c || !key || !ks || nblocks == 0 || nblocks > ((size_t)1 << 24))
         return fail(HHE_ERR_INVALID, "hhe_pasta3_plain_keystream: bad arguments");
     return keystream_into(c, key, first_block, nblocks, ks, c->lanes[0].stream);
@@ -50,6 +51,7 @@ extern "C" int hhe_pasta3_plain_keystream(hhe_ctx *c, const uint64_t *key, uint6
 extern "C" int hhe_pasta3_plain_crypt(hhe_ctx *c, const uint64_t *key, const uint64_t *in, size_t S, size_t nwords, int decrypt,
                                       uint64_t *out)
 {
+    HHE_LOCK(c);
     if (!c || !key || !in || !out || S == 0 || nwords == 0) return fail(HHE_ERR_INVALID, "hhe_pasta3_plain_crypt: bad arguments");
     const size_t nb = (nwords + PASTA_T - 1) / PASTA_T;  // ceil(size / plain_size) (pasta_3_plain.cpp:13)
     rt_stream st = c->lanes[0].stream;
@@ -69,6 +71,7 @@ extern "C" int hhe_pasta3_plain_crypt(hhe_ctx *c, const uint64_t *key, const uin
 
 extern "C" int hhe_decrypt(hhe_ctx *c, const uint64_t *sk, const uint64_t *ct, size_t B, uint64_t *vals)
 {
+    HHE_LOCK(c);
     if (!c || !sk || !ct || !vals || B == 0) return fail(HHE_ERR_INVALID, "hhe_decrypt: bad arguments");
     const int L = c->L;
     const size_t n = c->n, ln = (size_t)L * n;

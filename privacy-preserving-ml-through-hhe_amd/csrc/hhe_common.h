@@ -95,6 +95,13 @@ struct EltArgs {  // element-wise kernels over [count][N] polys, modulus = mod_b
     int b_cycle;  // poly of b = p % b_cycle (broadcast over the batch), 0 => same index
 };
 
+struct CopyItemsArgs {  // dst item (s * dst_stride + dst_off) <- src item (s * src_stride + src_off), `words` words each, s < count
+    const u64 *src;
+    u64 *dst;
+    size_t words, count;
+    size_t src_stride, src_off, dst_stride, dst_off;  // in items
+};
+
 struct GaloisArgs {  // out[p][k] = +-in[p][k * einv mod 2N]; poly p = (item b, limb j), p = b * L + j
     const u64 *in;
     u64 *out;

@@ -1,6 +1,7 @@
 // hhe_internal.h -- host-side context of libhhe_gfx950.so (not part of the C ABI).
 #pragma once
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "hhe_common.h"
@@ -38,9 +39,23 @@ struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `c
     u64 *ws_tp = nullptr;    // FC shared digits: [depth][B][L][K][N] digit transforms of the un-rotated c1 of each trie level
     size_t tp_cap = 0, tp_depth = 0;
     u32 *zero_flag = nullptr; // device flag of the chunk this lane is evaluating (shared-digit FC)
+    // host staging of small per-call inputs (mask values, pointer tables): it outlives the asynchronous copy, and the next
+    // user waits for that copy (ev_stage) before overwriting it
+    std::vector<u64> h_stage;
+    std::vector<const u64 *> h_ptrs;
+    void *ev_stage = nullptr;
+    bool stage_pending = false;
+    std::vector<std::pair<void *, void *>> prof_ev;  // hhe_ctx_profile: event pairs around the launches of ks_row_kernel on this lane's stream
+    size_t prof_used = 0;
 };
 
 struct hhe_ctx {
+    // every C-ABI entry point that takes the context holds this lock for its whole duration: concurrent callers (the
+    // reference's gRPC handlers run concurrently, CSPRPC.cpp:201-203) are serialised per context; different contexts are
+    // independent.  Recursive because hhe_decompose / the FC call other entry points.
+    std::recursive_mutex mu;
+    int profile = 0;               // hhe_ctx_profile: bracket the ks_row_kernel launches with timed events
+    u64 prof_items = 0;            // ciphertexts covered by the bracketed launches since the last read
     int logn = 0, K = 0, L = 0, device = 0;
     size_t n = 0;
     u64 t = 0;
@@ -77,6 +92,12 @@ struct hhe_ctx {
     std::map<u32, u64 *> d_gk;
     std::map<u32, u64 *> d_gk_shoup;           // per Galois key: Shoup quotients of the key words (fused row kernel), built on first use
     std::map<u32, u64 *> d_gk_corr;            // per Galois key: shared-digit correction [2][K][N] (KsCorrArgs), built on first FC use
+
+    // grow-only device scratch of hhe_decompose (all blocks of the records) and hhe_fc_row (per-chunk flags)
+    u64 *d_blocks = nullptr;
+    size_t blocks_cap = 0;   // words
+    u32 *d_flags = nullptr;
+    size_t flags_cap = 0;    // entries
 
     // PASTA public tables
     std::map<u64, BlockTables> blocks;
@@ -129,5 +150,12 @@ struct DevBuf {  // scoped device allocation (freed on every exit path unless re
     u64 *release() { u64 *r = (u64 *)p; p = nullptr; return r; }
 };
 
+struct CtxLock {  // null-safe scoped lock of a context (entry points check their arguments after taking it)
+    std::unique_lock<std::recursive_mutex> l;
+    explicit CtxLock(const hhe_ctx *c) { if (c) l = std::unique_lock<std::recursive_mutex>(const_cast<hhe_ctx *>(c)->mu); }
+};
+#define HHE_LOCK(c) CtxLock hhe_lock_guard_(c)
+
 void hhe_set_error(const std::string &msg);
 int lane_reserve(hhe_ctx *c, Lane &ln, size_t B);
+void sync_ctx(hhe_ctx *c);  // waits for every stream of the context

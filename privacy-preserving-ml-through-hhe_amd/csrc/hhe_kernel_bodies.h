@@ -464,6 +464,15 @@ HD void elt_body(const EltArgs &a, int op, size_t gid)
     a.out[gid] = r;
 }
 
+// strided gather / scatter of whole ciphertexts (16 bytes per lane): gid over [count][words / 2]
+HD void copy_items_body(const CopyItemsArgs &a, size_t gid)
+{
+    const size_t half = a.words >> 1;
+    const size_t s = gid / half, w = (gid % half) << 1;
+    if (s >= a.count) return;
+    st2(a.dst + (s * a.dst_stride + a.dst_off) * a.words + w, ld2(a.src + (s * a.src_stride + a.src_off) * a.words + w));
+}
+
 // GaloisTool::apply_galois as a gather (seal/util/galois.h:32)
 HD void galois_body(const GaloisArgs &a, size_t gid)
 {

@@ -50,7 +50,20 @@ void *rt_event_create()
     return (void *)e;
 }
 void rt_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+void *rt_event_create_timed()
+{
+    hipEvent_t e = nullptr;
+    if (rt_check(hipEventCreate(&e), "hipEventCreate")) return nullptr;
+    return (void *)e;
+}
+float rt_event_elapsed_ms(void *ev0, void *ev1)
+{
+    float ms = -1.f;
+    if (rt_check(hipEventElapsedTime(&ms, (hipEvent_t)ev0, (hipEvent_t)ev1), "hipEventElapsedTime")) return -1.f;
+    return ms;
+}
 int rt_event_record(void *ev, rt_stream s) { return rt_check(hipEventRecord((hipEvent_t)ev, (hipStream_t)s), "hipEventRecord"); }
+int rt_event_sync(void *ev) { return rt_check(hipEventSynchronize((hipEvent_t)ev), "hipEventSynchronize"); }
 int rt_stream_wait_event(rt_stream s, void *ev) { return rt_check(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0), "hipStreamWaitEvent"); }
 // ---------------------------------------------------------------- NTT
 // one-dimensional grids (gridDim.y is limited to 65535 polynomials): block -> (tile, poly), tiles per poly = 2^tiles_log
@@ -309,6 +322,7 @@ static inline unsigned nblocks(size_t total) { return (unsigned)((total + ELT_TH
 #define GID ((size_t)blockIdx.x * ELT_THREADS + threadIdx.x)
 
 __global__ void __launch_bounds__(ELT_THREADS) elt_kernel(EltArgs a, int op) { elt_body(a, op, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) copy_items_kernel(CopyItemsArgs a) { copy_items_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) galois_kernel(GaloisArgs a) { galois_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) perm_kernel(PermArgs a) { perm_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_mac_kernel(KsMacArgs a) { ks_mac_body(a, GID); }
@@ -331,6 +345,7 @@ __global__ void __launch_bounds__(ELT_THREADS) behz_floor_kernel(BehzFloorArgs a
     } while (0)
 
 void k_elt(const EltArgs &a, int op, rt_stream s) { LAUNCH1D(elt_kernel, (size_t)a.count << a.logn, s, a, op); }
+void k_copy_items(const CopyItemsArgs &a, rt_stream s) { LAUNCH1D(copy_items_kernel, a.count * (a.words >> 1), s, a); }
 void k_galois(const GaloisArgs &a, rt_stream s) { LAUNCH1D(galois_kernel, (size_t)a.count << a.logn, s, a); }
 void k_perm(const PermArgs &a, rt_stream s) { LAUNCH1D(perm_kernel, (size_t)a.count << a.logn, s, a); }
 template <int MODE> static void launch_ks_mac_t(const KsMacArgs &a, rt_stream s)

@@ -21,7 +21,10 @@ rt_stream rt_stream_create();
 void rt_stream_destroy(rt_stream s);
 void *rt_event_create();
 void rt_event_destroy(void *ev);
+void *rt_event_create_timed();                       // an event that hipEventElapsedTime accepts (profiling API only)
+float rt_event_elapsed_ms(void *ev0, void *ev1);     // both recorded and complete; < 0 on failure
 int rt_event_record(void *ev, rt_stream s);
+int rt_event_sync(void *ev);                         // host waits for the event
 int rt_stream_wait_event(rt_stream s, void *ev);
 const char *rt_last_error();
 
@@ -39,6 +42,7 @@ void k_ntt2_fwd_first(const NttArgs &a1, const NttArgs &a2, rt_stream s);  // fi
 bool k_ks_row_supported(int logn);
 void k_ks_row(const NttArgs &a, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s);
 void k_elt(const EltArgs &a, int op, rt_stream s);
+void k_copy_items(const CopyItemsArgs &a, rt_stream s);
 void k_galois(const GaloisArgs &a, rt_stream s);
 void k_perm(const PermArgs &a, rt_stream s);
 void k_ks_mac(const KsMacArgs &a, rt_stream s);

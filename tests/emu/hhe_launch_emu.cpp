@@ -25,7 +25,10 @@ rt_stream rt_stream_create() { static int dummy[8]; static int n = 0; return (rt
 void rt_stream_destroy(rt_stream) {}
 void *rt_event_create() { static int ev; return &ev; }
 void rt_event_destroy(void *) {}
+void *rt_event_create_timed() { static int ev; return &ev; }
+float rt_event_elapsed_ms(void *, void *) { return 0.f; }
 int rt_event_record(void *, rt_stream) { return 0; }
+int rt_event_sync(void *) { return 0; }
 int rt_stream_wait_event(rt_stream, void *) { return 0; }
 
 template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int S0, bool LAZY8 = false>
@@ -176,6 +179,7 @@ void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, t
         _Pragma("omp parallel for") for (long long g = 0; g < _t; g++) { call; } \
     } while (0)
 void k_elt(const EltArgs &a, int op, rt_stream) { LOOP((size_t)a.count << a.logn, elt_body(a, op, (size_t)g)); }
+void k_copy_items(const CopyItemsArgs &a, rt_stream) { LOOP(a.count * (a.words >> 1), copy_items_body(a, (size_t)g)); }
 void k_galois(const GaloisArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, galois_body(a, (size_t)g)); }
 void k_perm(const PermArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, perm_body(a, (size_t)g)); }
 template <int MODE> static void ks_mac_t_emu(const KsMacArgs &a)

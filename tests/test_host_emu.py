@@ -328,3 +328,35 @@ def test_fused_row_kernel_full_tiles(orc, api, emu_lib, mem, logn, bits):
     S.load_keys(X0)
     X0.transcipher(mem.to_dev(S.enc_key), cw, [ncw[0]], [3], out)
     assert (mem.to_host(out)[0] == ref).all()
+
+
+def test_two_threads_on_one_context_are_serialised(orc, api, emu_lib, mem, small):
+    """the reference's gRPC handlers call one cipher object concurrently (CSPRPC.cpp:201-203): every C-ABI entry point
+    holds the context's lock, so two threads on ONE context get the same words as sequential calls"""
+    import threading
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    small.load_keys(X)
+    pts = [[(3 * i + 1 + 17 * k) % 256 for i in range(128)] for k in range(2)]
+    blocks = [small.sym_blocks(orc, pt) for pt in pts]
+    refs = [small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[0], 4 + k) for k, (cw, _) in enumerate(blocks)]
+    outs = [mem.empty((1,) + small.O.ct_shape) for _ in range(2)]
+    errs = []
+
+    def work(k):
+        try:
+            cw, ncw = blocks[k]
+            for _ in range(2):
+                X.transcipher(mem.to_dev(small.enc_key), cw, ncw, [4 + k], outs[k])
+                d = mem.to_dev(mem.to_host(outs[k]))
+                X.add(d, d, d, 1)  # generic ops interleave with the other thread's transciphering
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        assert (mem.to_host(outs[k])[0] == refs[k]).all()

@@ -10,6 +10,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_W
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_IFETCH SQ_WAIT_INST_LDS" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_FLAT SQ_INSTS_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d $out/p$i -o out --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --cpu-baseline 0 "$@" > $out/p$i.json 2> $out/p$i.log || echo "pass $i failed"
+  rocprofv3 --pmc $set --kernel-trace -d $out/p$i -o out --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --cpu-baseline 0 --extras 0 --kernel-timing 0 "$@" > $out/p$i.json 2> $out/p$i.log || echo "pass $i failed"
 done
 echo done
