@@ -106,6 +106,9 @@ int hhe_rotate_columns(hhe_ctx *c, const uint64_t *ct_dptr, uint64_t *out_dptr, 
 int hhe_multiply(hhe_ctx *c, const uint64_t *a_dptr, const uint64_t *b_dptr, uint64_t *out3_dptr, size_t B);
 /* Evaluator::relinearize_inplace (seal/evaluator.h:301-304) size 3 -> 2 */
 int hhe_relinearize(hhe_ctx *c, const uint64_t *a3_dptr, uint64_t *out_dptr, size_t B);
+/* the same with the RelinKeys object of `slot` (hhe_set_relin_key_slot): Evaluator::relinearize_inplace(record, csp_rk) at
+ * src/examples/CSP/CSP.cpp:306 uses the CSP's keys, not the ones PASTA_SEAL was built with */
+int hhe_relinearize_slot(hhe_ctx *c, int slot, const uint64_t *a3_dptr, uint64_t *out_dptr, size_t B);
 
 /* ---- the hot path ---- */
 /* PASTA_SEAL::decomposition / HE_decrypt (src/pasta/pasta_3_seal.cpp:106-172 / :42-104), batched over

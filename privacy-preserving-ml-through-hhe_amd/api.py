@@ -33,7 +33,7 @@ _SYMBOLS = [
     "hhe_rotate_rows", "hhe_rotate_columns", "hhe_multiply", "hhe_relinearize",
     "hhe_pasta3_transcipher", "hhe_pasta3_clear_block_cache", "hhe_mask", "hhe_flatten", "hhe_fc_row", "hhe_decompose",
     "hhe_pasta3_block_randomness", "hhe_pasta3_plain_keystream", "hhe_pasta3_plain_crypt", "hhe_decrypt",
-    "hhe_ctx_profile", "hhe_ctx_profile_read",
+    "hhe_ctx_profile", "hhe_ctx_profile_read", "hhe_relinearize_slot",
 ]
 
 
@@ -180,8 +180,11 @@ class Context:
     def multiply(self, a, b, out3, B):
         self._chk(self.lib.hhe_multiply(self.h, _ptr(a), _ptr(b), _ptr(out3), C.c_size_t(B)))
 
-    def relinearize(self, a3, out, B):
-        self._chk(self.lib.hhe_relinearize(self.h, _ptr(a3), _ptr(out), C.c_size_t(B)))
+    def relinearize(self, a3, out, B, slot=None):
+        if slot is None:
+            self._chk(self.lib.hhe_relinearize(self.h, _ptr(a3), _ptr(out), C.c_size_t(B)))
+        else:
+            self._chk(self.lib.hhe_relinearize_slot(self.h, C.c_int(slot), _ptr(a3), _ptr(out), C.c_size_t(B)))
 
     # ---- hot path ----
     def transcipher(self, enc_key, cw, ncw, block_index, out, use_bsgs=False):

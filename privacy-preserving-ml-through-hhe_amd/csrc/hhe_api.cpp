@@ -641,6 +641,19 @@ extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, si
     if (rc) return rc;
     return op_relinearize(c, a3, out, B);
 }
+extern "C" int hhe_relinearize_slot(hhe_ctx *c, int slot, const uint64_t *a3, uint64_t *out, size_t B)
+{
+    HHE_LOCK(c);
+    if (!c || slot < 0 || slot >= HHE_RELIN_SLOTS) return fail(HHE_ERR_INVALID, "hhe_relinearize_slot: bad arguments");
+    if (!c->d_rk_slot[slot]) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
+    int rc = need(c, B);
+    if (rc) return rc;
+    u64 *saved = c->d_rk;
+    c->d_rk = c->d_rk_slot[slot];
+    rc = op_relinearize(c, a3, out, B);
+    c->d_rk = saved;
+    return rc;
+}
 
 // one chunk of the batch on the current lane (c->w): the schedule of PASTA_SEAL::decomposition (pasta_3_seal.cpp:123-170)
 static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d_diag, const u64 *const *d_rc,
