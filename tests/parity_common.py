@@ -241,13 +241,17 @@ def check_fc_variants(make_ctx, S, orc, mem, monkeypatch, n_in=37):
         X.close()
 
 
-def check_two_layer_chain(X, S, mem, n_in=24, seed=3):
+def check_two_layer_chain(X, S, mem, n_in=24, seed=3, w1_vals=None, x_vals=None):
     """BASELINE config 4 shape (FC -> packed_square -> FC, SEAL_Cipher.cpp:547-552 between two sealhelper FC rows):
-    ciphertext parity of the whole chain against the oracle's op sequence."""
+    ciphertext parity of the whole chain against the oracle's op sequence.  w1_vals / x_vals: first-layer weights (signed
+    integers, encoded mod t as the analyst does) and inputs; defaults are small seeded values."""
     O = S.O
     rng = np.random.default_rng(seed)
-    vi = O.encrypt(S.pk, O.encode(rng.integers(0, 4, n_in)), 61)
-    w1 = O.encrypt(S.pk, O.encode(rng.integers(0, 4, n_in)), 62)
+    x = np.asarray(x_vals if x_vals is not None else rng.integers(0, 4, n_in), dtype=np.int64)
+    w1i = np.asarray(w1_vals if w1_vals is not None else rng.integers(0, 4, n_in), dtype=np.int64)
+    assert len(x) == n_in and len(w1i) == n_in
+    vi = O.encrypt(S.pk, O.encode(x % S.t), 61)
+    w1 = O.encrypt(S.pk, O.encode(w1i % S.t), 62)
     w2 = O.encrypt(S.pk, O.encode(rng.integers(0, 4, n_in)), 63)
     ref1, _ = O.fc_row(vi, w1, S.rk, S.gk, n_in)
     ref_sq = O.relinearize(O.multiply(ref1, ref1), S.rk)
@@ -260,3 +264,6 @@ def check_two_layer_chain(X, S, mem, n_in=24, seed=3):
     assert (mem.to_host(d1)[0] == ref1).all()
     assert (mem.to_host(dsq)[0] == ref_sq).all()
     assert (mem.to_host(d2)[0] == ref2).all()
+    if O.noise_budget(S.sk, ref1, 8) > 0:  # the first layer decrypts to the plain integer dot product (FC == matMul, hhe_pktnn_examples.cpp:692-699)
+        got = int(O.decode(O.decrypt(S.sk, mem.to_host(d1)[0]))[n_in - 1])
+        assert got == int(np.dot(x, w1i)) % S.t
