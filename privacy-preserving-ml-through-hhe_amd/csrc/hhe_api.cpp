@@ -99,6 +99,20 @@ void op_multiply_plain_ntt(hhe_ctx *c, const u64 *ct, const u64 *D, const u64 *c
     op_ntt(c, out, B * 2 * c->L, 0, c->L, true);
 }
 
+// Shoup quotients floor(key * 2^64 / q_J) of a key-switch key ([L][2][K][N], as the key), built on first use by the
+// fused row kernel and cached per key (by its device address; dropped when the key is replaced)
+int ensure_key_shoup(hhe_ctx *c, const u64 *key, const u64 **out)
+{
+    auto it = c->d_key_shoup.find(key);
+    if (it != c->d_key_shoup.end()) { *out = it->second; return HHE_OK; }
+    DevBuf t(c->ksk_words() * 8);
+    if (!t.p) return dev_fail("key Shoup table alloc");
+    op_elt(c, ELT_SHOUP, key, nullptr, t.w(), (size_t)c->L * 2 * c->K, 0, c->K);
+    if (rt_sync(c->w->stream)) return dev_fail("key Shoup table");
+    *out = c->d_key_shoup[key] = t.release();
+    return HHE_OK;
+}
+
 // Evaluator::switch_key_inplace core.  d: item b at d + b*d_stride, [L][N] coefficient form.
 // out[b] = (base ? base polys selected by mask : 0) + key-switched pair.
 void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, const u64 *base, size_t base_stride,
@@ -108,6 +122,28 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
     NttArgs a = ntt_args(c, d, c->w->ws_T, B * L * K, 0, K);
     a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = d_stride; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
     a.store_op = STORE_LAZY;  // ks_mac reduces: digits may stay in [0,4q)
+    const u64 *key_s = nullptr;
+    if (k_ks_row_supported(c->logn) && ensure_key_shoup(c, key, &key_s) == HHE_OK) {
+        // N >= 4096: strided pass of the digit transforms, then ONE kernel for their row pass, the key inner product and
+        // the inverse row pass of all 2K sums (ks_row_kernel, as in the matmul loop), then the strided inverse passes with
+        // the mod-down fused into the store of the data limbs -- T and S never make a round trip
+        const size_t n = c->n;
+        u64 *W = c->w->ws_S, *Usp = c->w->ws_S + B * 2 * L * n;  // [B][2][L][N] | [B][2][N] inside [B][2][K][N]
+        k_ntt_pass(a, false, false, c->w->stream);
+        KsRowArgs x;
+        memset(&x, 0, sizeof(x));
+        x.key = key; x.key_s = key_s; x.U0 = W; x.U1 = W + (size_t)L * n; x.u_stride = (size_t)2 * L * n; x.Usp = Usp;
+        x.B = (int)B; x.L = L; x.K = K;
+        k_ks_row(a, x, nullptr, c->w->stream);
+        NttArgs as = ntt_args(c, Usp, Usp, B * 2, K - 1, 1);
+        as.store_op = STORE_RSP;
+        k_ntt_pass(as, true, true, c->w->stream);
+        NttArgs ad = ntt_args(c, W, W, B * 2 * L, 0, L);
+        ad.store_op = STORE_KSF; ad.aux_r = Usp; ad.aux_in = base; ad.base_stride = base_stride; ad.base_mask = base ? base_mask : 0;
+        ad.aux_out = out;
+        k_ntt_pass(ad, true, true, c->w->stream);
+        return;
+    }
     k_ntt(a, false, c->w->stream);
     KsMacArgs m;
     memset(&m, 0, sizeof(m));
@@ -391,20 +427,6 @@ struct ProfScope {
     ~ProfScope() { if (ln) rt_event_record(e1, ln->stream); }
 };
 
-// Shoup quotients floor(key * 2^64 / q_J) of a key-switch key ([L][2][K][N], as the key), built on first use by the
-// fused row kernel and cached per Galois element
-int ensure_key_shoup(hhe_ctx *c, u32 elt, const u64 *key, const u64 **out)
-{
-    auto it = c->d_gk_shoup.find(elt);
-    if (it != c->d_gk_shoup.end()) { *out = it->second; return HHE_OK; }
-    DevBuf t(c->ksk_words() * 8);
-    if (!t.p) return dev_fail("key Shoup table alloc");
-    op_elt(c, ELT_SHOUP, key, nullptr, t.w(), (size_t)c->L * 2 * c->K, 0, c->K);
-    if (rt_sync(c->w->stream)) return dev_fail("key Shoup table");
-    *out = c->d_gk_shoup[elt] = t.release();
-    return HHE_OK;
-}
-
 // PASTA_SEAL::diagonal (pasta_3_seal.cpp:370-413) as a fused pipeline: same ciphertext words as the
 // op-by-op schedule, 20 transforms per rotation step instead of 35 (DESIGN.md "fused matmul").
 //  - c0 stays in NTT form across the 127 rotate_rows(-1); c1 is kept in coefficient form because the
@@ -451,7 +473,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     const bool rowk = k_ks_row_supported(c->logn);
     const u64 *key_s = nullptr;
     if (rowk) {
-        int rc = ensure_key_shoup(c, g, key, &key_s);
+        int rc = ensure_key_shoup(c, key, &key_s);
         if (rc) return rc;
     }
     NttArgs k5;
@@ -469,7 +491,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             else k_ntt_pass(a, false, false, c->w->stream);
             KsRowArgs x;
             memset(&x, 0, sizeof(x));
-            x.key = key; x.key_s = key_s; x.S = c->w->ws_S + (size_t)(i & 1) * K * n; x.U1 = scr; x.Usp = r; x.B = (int)B; x.L = L; x.K = K;
+            x.key = key; x.key_s = key_s; x.S = c->w->ws_S + (size_t)(i & 1) * K * n; x.U1 = scr; x.u_stride = ln; x.Usp = r; x.B = (int)B; x.L = L; x.K = K;
             x.acc = accp1; x.mul_ptrs = d_pdiag_ptrs; x.mul_shift = shift;
             {
                 ProfScope prof(c, *c->w, B);

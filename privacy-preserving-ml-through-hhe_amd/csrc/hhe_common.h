@@ -39,6 +39,7 @@ enum NttStoreOp {
     STORE_KS1 = 6,         // inv: (v - r_1 + half) * q_sp^-1, written through the Galois map into aux_out
     STORE_KS0 = 7,         // fwd: NTT-domain key-switch finish of c0 + permuted-frame diagonal MAC
     STORE_RACC = 9,        // inv (special limb): r = v + half mod q_sp, then acc[b][k][j] += half_j - (r mod q_j) for every data limb j
+    STORE_KSF = 10,        // inv, polys [B][2][L]: generic key-switch finish (v - r_k + half) * q_sp^-1 (+ base poly k) into aux_out
     STORE_LAZY = 8         // fwd: leave the result in the lazy range [0,4q) (consumer reduces: key-switch inner product)
 };
 
@@ -79,9 +80,11 @@ struct NttArgs {
     // fused key-switch epilogues (matmul pipeline)
     int L, K;
     u32 gal_elt;        // KS1: coefficient-domain Galois element (0 = identity); KS0: NTT-domain element
-    const u64 *aux_r;   // KS1: r [B][2][N] (poly 1 used);  KS0: S [B][2][K][N] (poly 0, limb j)
-    const u64 *aux_in;  // KS0: c0 (NTT form) of the current state [B][L][N]
-    u64 *aux_out;       // KS1: d [B][L][N];  KS0: c0 (NTT form) of the next state [B][L][N]
+    const u64 *aux_r;   // KS1 / KSF: r [B][2][N] (KS1: poly 1);  KS0: S [B][2][K][N] (poly 0, limb j)
+    const u64 *aux_in;  // KS0: c0 (NTT form) of the current state [B][L][N];  KSF: base ciphertexts (item b at aux_in + b * base_stride) or null
+    u64 *aux_out;       // KS1: d [B][L][N];  KS0: c0 (NTT form) of the next state [B][L][N];  KSF: out [B][2][L][N]
+    size_t base_stride; // KSF: words between the items of aux_in
+    int base_mask;      // KSF: bit k set => add base poly k
     KsConsts ks;
 };
 
@@ -136,8 +139,10 @@ struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
 struct KsRowArgs {
     const u64 *key;      // [L][2][K][N]
     const u64 *key_s;    // Shoup quotients floor(key * 2^64 / q_J), same layout
-    u64 *S;              // [B][2][K][N]: only S_0[j], j < L, is written (NTT form, canonical) -- the c0 branch reads it
-    u64 *U1;             // [B][L][N]: inverse row pass of S_1[j], j < L
+    u64 *S;              // [B][2][K][N]: only S_0[j], j < L, is written (NTT form, canonical) -- the c0 branch reads it; null with U0
+    u64 *U0;             // generic key switch: inverse row pass of S_0[j] (item b, limb j at U0 + b * u_stride + j * N); else null
+    u64 *U1;             // inverse row pass of S_1[j], j < L (item b, limb j at U1 + b * u_stride + j * N)
+    size_t u_stride;     // words between items in U0 / U1
     u64 *Usp;            // [B][2][N]: inverse row pass of S_0[special], S_1[special]
     int B, L, K;
     // fused matmul: acc[b][J][n] += T[b][J][J][n] * mul_ptrs[b][mul_shift + J*N + n] for J < L (the I = J digit)

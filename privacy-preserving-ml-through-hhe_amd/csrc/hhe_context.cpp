@@ -409,7 +409,7 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
     for (auto &p : c->d_rk_slot) rt_free(p);
     for (auto &kv : c->d_gk) rt_free(kv.second);
     for (auto &kv : c->d_gk_corr) rt_free(kv.second);
-    for (auto &kv : c->d_gk_shoup) rt_free(kv.second);
+    for (auto &kv : c->d_key_shoup) rt_free(kv.second);
     rt_free(c->d_feistel_mask);
     rt_free(c->d_blocks); rt_free(c->d_flags);
     rt_free(c->d_tables); rt_free(c->d_mods); rt_free(c->d_behz); rt_free(c->d_slot_map);
@@ -502,6 +502,10 @@ extern "C" uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i)
 
 static int upload_key(hhe_ctx *c, u64 *&slot, const uint64_t *ksk)
 {
+    if (slot) {  // the Shoup table of the words being replaced
+        auto sh = c->d_key_shoup.find(slot);
+        if (sh != c->d_key_shoup.end()) { sync_ctx(c); rt_free(sh->second); c->d_key_shoup.erase(sh); }
+    }
     if (!slot) slot = (u64 *)rt_malloc(c->ksk_words() * 8);
     if (!slot || rt_h2d(slot, ksk, c->ksk_words() * 8, c->lanes[0].stream) || rt_sync(c->lanes[0].stream)) {
         hhe_set_error(std::string("key upload failed: ") + rt_last_error());
@@ -524,8 +528,7 @@ extern "C" int hhe_set_galois_key(hhe_ctx *c, uint32_t elt, const uint64_t *ksk)
     if (!c || !ksk || !(elt & 1) || elt >= 2 * c->n) { hhe_set_error("hhe_set_galois_key: invalid Galois element"); return HHE_ERR_INVALID; }
     auto corr = c->d_gk_corr.find(elt);  // derived from the key being replaced
     if (corr != c->d_gk_corr.end()) { rt_sync(c->lanes[0].stream); rt_free(corr->second); c->d_gk_corr.erase(corr); }
-    auto sh = c->d_gk_shoup.find(elt);
-    if (sh != c->d_gk_shoup.end()) { rt_sync(c->lanes[0].stream); rt_free(sh->second); c->d_gk_shoup.erase(sh); }
+
     u64 *&slot = c->d_gk[elt];
     return upload_key(c, slot, ksk);
 }

@@ -90,7 +90,7 @@ struct hhe_ctx {
     u64 *d_rk = nullptr;                       // slot 0 (transciphering)
     u64 *d_rk_slot[HHE_RELIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     std::map<u32, u64 *> d_gk;
-    std::map<u32, u64 *> d_gk_shoup;           // per Galois key: Shoup quotients of the key words (fused row kernel), built on first use
+    std::map<const u64 *, u64 *> d_key_shoup;  // per key-switch key (by device address): Shoup quotients of its words (fused row kernel), built on first use
     std::map<u32, u64 *> d_gk_corr;            // per Galois key: shared-digit correction [2][K][N] (KsCorrArgs), built on first FC use
 
     // grow-only device scratch of hhe_decompose (all blocks of the records) and hhe_fc_row (per-chunk flags)

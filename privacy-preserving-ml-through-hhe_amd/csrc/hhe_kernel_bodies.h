@@ -302,6 +302,11 @@ HD StorePre ntt_store_fetch(const NttArgs &a, const NttGeom &g, size_t pbase, in
     if (!LAST) return p;
     if (INVERSE) {
         if (a.store_op == STORE_KS1) p.s = ld2(a.aux_r + ((size_t)(g.poly / a.L) * 2 + 1) * g.n + gi);
+        else if (a.store_op == STORE_KSF) {
+            const size_t bk = g.poly / a.L;  // (item, k)
+            p.s = ld2(a.aux_r + bk * g.n + gi);
+            if ((a.base_mask >> (bk & 1)) & 1) p.d = ld2(a.aux_in + (bk >> 1) * a.base_stride + ((bk & 1) * a.L + g.poly % a.L) * g.n + gi);
+        }
     } else if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
         const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
         p.d = ld2(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);
@@ -340,6 +345,19 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
                 ac.b = addmod(ac.b, submod(a.ks.half_mod[j], reduce64(v[1], mj), mj.q), mj.q);
                 st2(ap, ac);
             }
+            return;
+        }
+        else if (a.store_op == STORE_KSF) {  // Evaluator::switch_key_inplace mod-down, poly = (item, k, j)
+            const int j = g.poly % a.L;
+            const bool base = (a.base_mask >> ((g.poly / a.L) & 1)) & 1;
+            const u64 rr[2] = {pre.s.a, pre.s.b}, bb[2] = {pre.d.a, pre.d.b};
+            u64 o[2];
+            for (int k = 0; k < 2; k++) {
+                u64 t = addmod(submod(v[k], reduce64(rr[k], m), q), a.ks.half_mod[j], q);
+                t = shoup_mul(t, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
+                o[k] = base ? addmod(t, bb[k], q) : t;
+            }
+            st2(a.aux_out + pbase + gi, U2{o[0], o[1]});
             return;
         }
         else if (a.store_op == STORE_KS1) {

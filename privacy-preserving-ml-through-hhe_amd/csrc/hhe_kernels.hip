@@ -278,11 +278,17 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_THREADS / 64) ks_row_kern
         __syncthreads();
     }
     if (J < x.L) {
-        ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
+        if (x.U0) {  // generic key switch: S_0[j] is inverse-transformed as well
+            ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
+            __syncthreads();
+            ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
+            ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U0 + (size_t)b * x.u_stride + (size_t)J * n);
+            __syncthreads();
+        } else ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
         ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
         __syncthreads();
         ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
-        ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U1 + ((size_t)b * x.L + J) * n);
+        ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U1 + (size_t)b * x.u_stride + (size_t)J * n);
     } else {
         ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
         __syncthreads();

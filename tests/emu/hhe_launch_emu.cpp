@@ -145,8 +145,9 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
                     for (int t = 0; t < T; t++) ks_row_store_phase<LOGM, CC>(a, bx, J, t, lds.data(), out);
                 };
                 if (J < x.L) {
-                    for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), A0(t), x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
-                    inverse_to(acc1, x.U1 + ((size_t)b * x.L + J) * n);
+                    if (x.U0) inverse_to(acc0, x.U0 + (size_t)b * x.u_stride + (size_t)J * n);
+                    else for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), A0(t), x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
+                    inverse_to(acc1, x.U1 + (size_t)b * x.u_stride + (size_t)J * n);
                 } else {
                     inverse_to(acc0, x.Usp + ((size_t)b * 2 + 0) * n);
                     inverse_to(acc1, x.Usp + ((size_t)b * 2 + 1) * n);

@@ -360,3 +360,12 @@ def test_two_threads_on_one_context_are_serialised(orc, api, emu_lib, mem, small
     assert not errs, errs
     for k in range(2):
         assert (mem.to_host(outs[k])[0] == refs[k]).all()
+
+
+def test_generic_key_switch_through_the_row_kernel(orc, api, emu_lib, mem):
+    """N >= 4096: Evaluator::switch_key (rotations by any key, relinearize) also runs through ks_row_kernel, here with the
+    inverse row pass of S_0 as well and the mod-down fused into the store of the last inverse pass (STORE_KSF)"""
+    S = Setup(orc, 12, [50, 50, 50, 50])
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    pc.check_ops(X, S, mem, B=2, seed=21)
