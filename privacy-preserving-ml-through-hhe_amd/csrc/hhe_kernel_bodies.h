@@ -491,20 +491,28 @@ HD void copy_items_body(const CopyItemsArgs &a, size_t gid)
     st2(a.dst + (s * a.dst_stride + a.dst_off) * a.words + w, ld2(a.src + (s * a.src_stride + a.src_off) * a.words + w));
 }
 
-// GaloisTool::apply_galois as a gather (seal/util/galois.h:32)
+// GaloisTool::apply_galois as a gather (seal/util/galois.h:32): gid over [count][N / 2], two adjacent output
+// coefficients per lane (16-byte store / read-modify-write, two 8-byte gathers)
 HD void galois_body(const GaloisArgs &a, size_t gid)
 {
     const u32 n = 1u << a.logn;
-    const size_t p = gid >> a.logn;
+    const size_t p = gid >> (a.logn - 1);
     if (p >= (size_t)a.count) return;
-    const u32 k = (u32)(gid & (n - 1));
+    const u32 k = (u32)(gid & ((n >> 1) - 1)) << 1;
     const size_t item = p / a.L, limb = p % a.L;
     const u64 q = a.mods[limb].q;
-    const u32 j = (u32)(((u64)k * a.einv) & (2 * n - 1));
     const u64 *src = a.in + item * a.in_item_stride + limb * n;
-    u64 v = (j < n) ? src[j] : negmod(src[j - n], q);
+    const u32 j0 = (u32)(((u64)k * a.einv) & (2 * n - 1)), j1 = (u32)((j0 + a.einv) & (2 * n - 1));
+    U2 v;
+    v.a = (j0 < n) ? src[j0] : negmod(src[j0 - n], q);
+    v.b = (j1 < n) ? src[j1] : negmod(src[j1 - n], q);
     u64 *o = a.out + item * a.out_item_stride + limb * n + k;
-    *o = a.accumulate ? addmod(*o, v, q) : v;
+    if (a.accumulate) {
+        const U2 c = ld2(o);
+        v.a = addmod(c.a, v.a, q);
+        v.b = addmod(c.b, v.b, q);
+    }
+    st2(o, v);
 }
 
 // NTT-domain Galois gather, optionally multiply-accumulating with a per-item table: gid over [count][N]

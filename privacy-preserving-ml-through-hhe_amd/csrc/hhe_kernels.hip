@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(ELT_THREADS) behz_floor_kernel(BehzFloorArgs a
 
 void k_elt(const EltArgs &a, int op, rt_stream s) { LAUNCH1D(elt_kernel, (size_t)a.count << a.logn, s, a, op); }
 void k_copy_items(const CopyItemsArgs &a, rt_stream s) { LAUNCH1D(copy_items_kernel, a.count * (a.words >> 1), s, a); }
-void k_galois(const GaloisArgs &a, rt_stream s) { LAUNCH1D(galois_kernel, (size_t)a.count << a.logn, s, a); }
+void k_galois(const GaloisArgs &a, rt_stream s) { LAUNCH1D(galois_kernel, (size_t)a.count << (a.logn - 1), s, a); }
 void k_perm(const PermArgs &a, rt_stream s) { LAUNCH1D(perm_kernel, (size_t)a.count << a.logn, s, a); }
 template <int MODE> static void launch_ks_mac_t(const KsMacArgs &a, rt_stream s)
 {

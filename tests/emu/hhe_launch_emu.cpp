@@ -181,7 +181,7 @@ void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, t
     } while (0)
 void k_elt(const EltArgs &a, int op, rt_stream) { LOOP((size_t)a.count << a.logn, elt_body(a, op, (size_t)g)); }
 void k_copy_items(const CopyItemsArgs &a, rt_stream) { LOOP(a.count * (a.words >> 1), copy_items_body(a, (size_t)g)); }
-void k_galois(const GaloisArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, galois_body(a, (size_t)g)); }
+void k_galois(const GaloisArgs &a, rt_stream) { LOOP((size_t)a.count << (a.logn - 1), galois_body(a, (size_t)g)); }
 void k_perm(const PermArgs &a, rt_stream) { LOOP((size_t)a.count << a.logn, perm_body(a, (size_t)g)); }
 template <int MODE> static void ks_mac_t_emu(const KsMacArgs &a)
 {
