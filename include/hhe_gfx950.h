@@ -121,7 +121,10 @@ int hhe_relinearize_slot(hhe_ctx *c, int slot, const uint64_t *a3_dptr, uint64_t
 int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key_dptr, const uint64_t *cw_hptr,
                            const uint32_t *ncw_hptr, const uint64_t *block_index_hptr, size_t B,
                            int use_bsgs, uint64_t *out_dptr);
-/* drop cached per-block public tables (matrices depend only on (nonce, block index)) */
+/* drop cached per-block public tables (matrices depend only on (nonce, block index)).  The cache is unbounded and grows by
+ * (4 x 128 x L + 4) x N words per distinct block counter on first use -- 384 MiB at N = 2^15, L = 3; 1.07 GiB at the
+ * reference defaults N = 2^14, L = 8; the babystep-giantstep variant adds the same again -- so a caller that walks through
+ * many block counters (long records) calls this between batches. */
 void hhe_pasta3_clear_block_cache(hhe_ctx *c);
 /* SEALZpCipher::mask (src/pasta/SEAL_Cipher.cpp:161-166): mask_vals_hptr[count], shared by the batch */
 int hhe_mask(hhe_ctx *c, const uint64_t *ct_dptr, const uint64_t *mask_vals_hptr, size_t count,
