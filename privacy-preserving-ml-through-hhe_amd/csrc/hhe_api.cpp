@@ -274,7 +274,7 @@ int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
     pasta3_block_randomness(c->t, PASTA_NONCE, block, mats.data(), rcs.data());
     const bool fused = c->matmul_mode == 1;
     DevBuf d_mats(mats.size() * 8), d_rcs(rcs.size() * 8), slots(ndiag * n * 8), diag(ndiag * L * n * 8),
-        rc((size_t)(PASTA_R + 1) * n * 8), pdiag(fused ? ndiag * L * n * 8 : 8);
+        rc((size_t)(PASTA_R + 1) * n * 8), pdiag(fused ? 2 * ndiag * L * n * 8 : 8);  // pdiag | its Shoup quotients
     if (!d_mats.p || !d_rcs.p || !slots.p || !diag.p || !rc.p || !pdiag.p) return dev_fail("block table alloc");
     rt_h2d(d_mats.p, mats.data(), mats.size() * 8, c->w->stream);
     rt_h2d(d_rcs.p, rcs.data(), rcs.size() * 8, c->w->stream);
@@ -295,6 +295,7 @@ int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
         p.in = diag.w(); p.out = pdiag.w(); p.mods = c->d_mods; p.logn = c->logn; p.count = (int)(ndiag * L); p.L = L;
         p.out_item_stride = (size_t)L * n; p.elt = galois_elt_from_step(c, -1);
         k_perm(p, c->w->stream);
+        op_elt(c, ELT_SHOUP, pdiag.w(), nullptr, pdiag.w() + ndiag * L * n, ndiag * L, 0, L);
     }
     if (rt_sync(c->w->stream)) return dev_fail("block tables");
     BlockTables bt;
@@ -471,6 +472,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     // N >= 4096: the row pass of the digit transforms, the key inner product and the inverse row pass run as ONE kernel
     // (ks_row_kernel): T and the sums that are inverse-transformed next never reach memory
     const bool rowk = k_ks_row_supported(c->logn);
+    const size_t pdiag_words = (size_t)(PASTA_R + 1) * PASTA_T * ln;  // the Shoup quotients of pdiag follow the table (ensure_block)
     const u64 *key_s = nullptr;
     if (rowk) {
         int rc = ensure_key_shoup(c, key, &key_s);
@@ -492,7 +494,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             KsRowArgs x;
             memset(&x, 0, sizeof(x));
             x.key = key; x.key_s = key_s; x.S = c->w->ws_S + (size_t)(i & 1) * K * n; x.U1 = scr; x.u_stride = ln; x.Usp = r; x.B = (int)B; x.L = L; x.K = K;
-            x.acc = accp1; x.mul_ptrs = d_pdiag_ptrs; x.mul_shift = shift;
+            x.acc = accp1; x.mul_ptrs = d_pdiag_ptrs; x.mul_shift = shift; x.mul_s_off = pdiag_words;
             {
                 ProfScope prof(c, *c->w, B);
                 k_ks_row(a, x, k5_pending ? &k5 : nullptr, c->w->stream);
@@ -536,7 +538,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             a.src_item_polys = L; a.src_item_stride = 2 * n; a.src_div = L; a.load_op = LOAD_RNEG;
             a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.acc = accp0;
             a.aux_r = c->w->ws_S + (rowk ? (size_t)(i & 1) * K * n : 0);
-            a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g;
+            a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g; a.mul_s_off = pdiag_words;
             if (merge || rowk) { k5 = a; k5_pending = true; }  // launched in the grid of the next step's digit transforms
             else k_ntt(a, false, c->w->stream);
         }

@@ -75,6 +75,7 @@ struct NttArgs {
     const u64 *mul;
     const u64 *const *mul_ptrs;
     size_t mul_shift;
+    size_t mul_s_off;   // KS0: > 0 => the Shoup quotients of the multiplier table follow it at this word offset (pdiag of the fused matmul)
     int mul_cycle, mul_item_polys;
     u64 *acc;       // STORE_MAC / DIGIT_DIAG / KS0: accumulator polys
     // fused key-switch epilogues (matmul pipeline)
@@ -149,6 +150,7 @@ struct KsRowArgs {
     u64 *acc;
     const u64 *const *mul_ptrs;
     size_t mul_shift;
+    size_t mul_s_off;    // > 0: Shoup quotients of the multiplier table at this word offset behind it
 };
 
 // Correction of the shared-digit key switch (DESIGN.md "FC rotation trie"): the digit d_I of galois_g(c1) differs from

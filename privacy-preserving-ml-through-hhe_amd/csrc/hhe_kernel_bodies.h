@@ -403,8 +403,14 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             const U2 d = pre.d, s0 = pre.s;
             U2 acc = pre.acc;
             const u64 g0 = pre.gp.a, g1 = pre.gp.b;
-            acc.a = addmod(acc.a, mulmod(g0, d.a, m), q);
-            acc.b = addmod(acc.b, mulmod(g1, d.b, m), q);
+            if (a.mul_s_off) {  // plaintext diagonal with its Shoup quotient: a lazy product in [0,2q) instead of a Barrett product
+                const U2 ds = ld2(a.mul_ptrs[g.poly / a.L] + a.mul_shift + a.mul_s_off + (size_t)j * g.n + gi);
+                acc.a += shoup_lazy(g0, d.a, ds.a, q); acc.a -= (acc.a >= q2) ? q2 : 0; acc.a -= (acc.a >= q) ? q : 0;
+                acc.b += shoup_lazy(g1, d.b, ds.b, q); acc.b -= (acc.b >= q2) ? q2 : 0; acc.b -= (acc.b >= q) ? q : 0;
+            } else {
+                acc.a = addmod(acc.a, mulmod(g0, d.a, m), q);
+                acc.b = addmod(acc.b, mulmod(g1, d.b, m), q);
+            }
             st2(a.acc + pbase + gi, acc);
             U2 o;
             o.a = addmod(g0, shoup_mul(submod(s0.a, v[0], q), a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q), q);
@@ -709,11 +715,17 @@ HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, i
                 a1 -= (a1 >= q4) ? q4 : 0; a1 -= (a1 >= q2) ? q2 : 0;
             }
         }
-        if (diag) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product (lazy input, Barrett accepts it)
+        if (diag) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product (lazy input)
             const U2 d = ld2(dptr + gi);
             U2 ac = ld2(ap + gi);
-            ac.a = addmod(ac.a, mulmod(v0, d.a, m), q);
-            ac.b = addmod(ac.b, mulmod(v1, d.b, m), q);
+            if (x.mul_s_off) {  // Shoup product with the table's quotients
+                const U2 ds = ld2(dptr + x.mul_s_off + gi);
+                ac.a += shoup_lazy(v0, d.a, ds.a, q); ac.a -= (ac.a >= q2) ? q2 : 0; ac.a -= (ac.a >= q) ? q : 0;
+                ac.b += shoup_lazy(v1, d.b, ds.b, q); ac.b -= (ac.b >= q2) ? q2 : 0; ac.b -= (ac.b >= q) ? q : 0;
+            } else {
+                ac.a = addmod(ac.a, mulmod(v0, d.a, m), q);
+                ac.b = addmod(ac.b, mulmod(v1, d.b, m), q);
+            }
             st2(ap + gi, ac);
         }
     }
