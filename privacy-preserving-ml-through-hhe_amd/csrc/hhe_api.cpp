@@ -895,8 +895,8 @@ struct NafNode {
     int mult = 0;                 // how many i end exactly here
     std::vector<int> kids;
 };
-struct FcLeafAcc {  // sums over the leaves of the trie (DESIGN.md "FC rotation trie")
-    u64 *accG, *accS, *accH, *rscr;
+struct FcLeafAcc {  // sums over the leaves of the trie (DESIGN.md "FC rotation trie"): accS in the NTT domain, accH in the
+    u64 *accS, *accH, *rscr;  // coefficient domain (rounding terms + q_sp * galois(c0), added by the RACC epilogue)
 };
 // A leaf's ciphertext is only ever added into the result.  Key switching is linear up to the rounding term, so for
 // leaves the inverse transforms of S_k[j] are postponed: sum S_k[j] over all leaves in the NTT domain, sum the rounding
@@ -911,9 +911,8 @@ int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t
     GaloisArgs g;
     memset(&g, 0, sizeof(g));
     g.mods = c->d_mods; g.logn = c->logn; g.count = (int)(B * L); g.L = L; g.einv = (u32)nt_invmod(elt, 2 * n);
-    g.in = parent; g.in_item_stride = 2 * ln; g.out = acc.accG; g.out_item_stride = ln; g.accumulate = 1;
-    k_galois(g, c->w->stream);
-    g.in = parent + ln; g.out = c->w->ws_d; g.accumulate = 0;
+    g.in_item_stride = 2 * ln; g.out_item_stride = ln;
+    g.in = parent + ln; g.out = c->w->ws_d; g.accumulate = 0;  // galois(c0) joins the sums inside the RACC epilogue below
     k_galois(g, c->w->stream);
     NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
     a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
@@ -926,6 +925,7 @@ int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t
     k_ks_mac(m, c->w->stream);
     NttArgs r = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, acc.rscr, B * 2, K - 1, 1);
     r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RACC; r.acc = acc.accH;
+    r.aux_in = parent; r.base_stride = 2 * ln; r.gal_einv = (u32)nt_invmod(elt, 2 * n);
     k_ntt(r, true, c->w->stream);
     return HHE_OK;
 }
@@ -987,29 +987,27 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
     if (rc) return rc;
     const int L = c->L, K = c->K;
     const size_t n = c->n, ln = (size_t)L * n;
-    GaloisArgs g;
-    memset(&g, 0, sizeof(g));
-    g.mods = c->d_mods; g.logn = c->logn; g.count = (int)(B * L); g.L = L; g.einv = (u32)nt_invmod(elt, 2 * n);
-    g.in = parent; g.in_item_stride = 2 * ln;
-    if (leaf) { g.out = leaf->accG; g.out_item_stride = ln; g.accumulate = 1; }
-    else { g.out = cur; g.out_item_stride = 2 * ln; }   // c0' = galois(c0): base of the key switch
-    k_galois(g, c->w->stream);
+    const u32 einv = (u32)nt_invmod(elt, 2 * n);  // galois(c0) is gathered inside the epilogues (RACC for leaves, KSF otherwise)
     KsMacArgs m;
     memset(&m, 0, sizeof(m));
     m.T = tp; m.key = it->second; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
     m.perm_elt = elt; m.corr = corr;
+    u64 *Usp = c->w->ws_S + B * 2 * L * n;  // split output [B][2][L][N] | [B][2][N] (non-leaf children)
     if (leaf) m.s_acc = leaf->accS;
+    else m.S_sp = Usp;
     k_ks_mac(m, c->w->stream);
     if (leaf) {
         NttArgs r = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, leaf->rscr, B * 2, K - 1, 1);
         r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RACC; r.acc = leaf->accH;
+        r.aux_in = parent; r.base_stride = 2 * ln; r.gal_einv = einv;
         k_ntt(r, true, c->w->stream);
         return HHE_OK;
     }
-    op_ntt(c, c->w->ws_S, B * 2 * K, 0, K, true);
-    KsFinishArgs f = c->ksf;
-    f.S = c->w->ws_S; f.base = cur; f.base_item_stride = 2 * ln; f.base_mask = 1; f.out = cur; f.B = (int)B;
-    k_ks_finish(f, c->w->stream);
+    // all 2K sums are inverse-transformed; the mod-down rides in the store of the data limbs' last pass (STORE_KSF)
+    op_ntt(c, Usp, B * 2, K - 1, 1, true, STORE_RSP);
+    NttArgs ad = ntt_args(c, c->w->ws_S, c->w->ws_S, B * 2 * L, 0, L);
+    ad.store_op = STORE_KSF; ad.aux_r = Usp; ad.aux_in = parent; ad.base_stride = 2 * ln; ad.base_mask = 1; ad.gal_einv = einv; ad.aux_out = cur;
+    k_ntt(ad, true, c->w->stream);
     return HHE_OK;
 }
 int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out,
@@ -1184,16 +1182,15 @@ static int fc_row_chunk(hhe_ctx *c, Lane &lane, bool shared, const uint64_t *vi,
         };
         if (!c->fc_leaf_sums) return dfs(nullptr);
         FcLeafAcc acc;
-        acc.accS = ln.ws_ct[0]; acc.accH = ln.ws_ct[1]; acc.accG = ln.ws_ct[2]; acc.rscr = ln.ws_ct[2] + bln;
+        acc.accS = ln.ws_ct[0]; acc.accH = ln.ws_ct[1]; acc.rscr = ln.ws_ct[2];
         rt_memset(acc.accS, 0, 2 * bln * 8, ln.stream);
         rt_memset(acc.accH, 0, 2 * bln * 8, ln.stream);
-        rt_memset(acc.accG, 0, bln * 8, ln.stream);
         int r = dfs(&acc);
         if (r) return r;
         op_ntt(c, acc.accS, B * 2 * L, 0, L, true);
         LeafSumArgs ls;
         memset(&ls, 0, sizeof(ls));
-        ls.accG = acc.accG; ls.accS = acc.accS; ls.accH = acc.accH; ls.out = out; ls.mods = c->d_mods; ls.logn = c->logn;
+        ls.accS = acc.accS; ls.accH = acc.accH; ls.out = out; ls.mods = c->d_mods; ls.logn = c->logn;
         ls.B = (int)B; ls.L = L; ls.ks = c->ksc;
         k_leaf_sum(ls, ln.stream);
         return HHE_OK;

@@ -49,6 +49,8 @@ struct KsConsts {
     u64 half_mod[HHE_MAXL];   // half mod q_j
     u64 qsp_inv[HHE_MAXL];    // q_sp^-1 mod q_j
     u64 qsp_inv_s[HHE_MAXL];
+    u64 qsp_mod[HHE_MAXL];    // q_sp mod q_j (FC leaf sums: galois(c0) enters the sum that is later multiplied by q_sp^-1)
+    u64 qsp_mod_s[HHE_MAXL];
 };
 
 struct NttArgs {
@@ -81,6 +83,7 @@ struct NttArgs {
     // fused key-switch epilogues (matmul pipeline)
     int L, K;
     u32 gal_elt;        // KS1: coefficient-domain Galois element (0 = identity); KS0: NTT-domain element
+    u32 gal_einv;       // KSF / RACC: > 0 => the base / the c0 term is galois(c0) gathered on the fly: elt^-1 mod 2N (aux_in = the un-rotated ciphertexts)
     const u64 *aux_r;   // KS1 / KSF: r [B][2][N] (KS1: poly 1);  KS0: S [B][2][K][N] (poly 0, limb j)
     const u64 *aux_in;  // KS0: c0 (NTT form) of the current state [B][L][N];  KSF: base ciphertexts (item b at aux_in + b * base_stride) or null
     u64 *aux_out;       // KS1: d [B][L][N];  KS0: c0 (NTT form) of the next state [B][L][N];  KSF: out [B][2][L][N]
@@ -132,6 +135,9 @@ struct KsMacArgs {  // S[b][k][J][n] = sum_I T[b][I][J][n] * key[I][k][J][n]
     // as the NTT-domain index map while reading T, and corr[k][J][n] (KsCorrArgs) is added to the sums
     u32 perm_elt;
     const u64 *corr;  // [2][K][N]
+    // optional split output (key switch finished by the fused STORE_KSF pass): the data limbs go to S as [B][2][L][N] and the
+    // special limb to S_sp [B][2][N] instead of S [B][2][K][N]
+    u64 *S_sp;
 };
 // Fused key-switch row kernel (ks_row_kernel): for one (item b, key limb J, row tile) it runs the forward ROW pass of the
 // L digit transforms T[b][I][J] (their strided pass has already run), multiplies each finished tile with key[I][0..1][J]
@@ -177,10 +183,9 @@ struct PermArgs {  // NTT-domain Galois permutation: out[p][x] (op)= in[p][pi_el
     size_t mul_shift;
 };
 
-struct LeafSumArgs {  // out[b][k][j] += (k == 0 ? accG[b][j] : 0) + qsp_inv_j * (accS[b][k][j] (INTT'd) + accH[b][k][j])
-    const u64 *accG;  // [B][L][N] sum of galois(c0) of the leaf parents
+struct LeafSumArgs {  // out[b][k][j] += qsp_inv_j * (accS[b][k][j] (INTT'd) + accH[b][k][j])
     const u64 *accS;  // [B][2][L][N] coefficient form (after INTT)
-    const u64 *accH;  // [B][2][L][N]
+    const u64 *accH;  // [B][2][L][N] rounding terms, and for k = 0 q_sp * galois(c0) of the leaf parents
     u64 *out;         // [B][2][L][N]
     const ModDev *mods;
     int logn, B, L;
@@ -199,6 +204,8 @@ struct KsFinishArgs {  // SURVEY A.4 mod-down; S already INTT'd (coefficient for
     u64 half_mod[HHE_MAXL];   // half mod q_j
     u64 qsp_inv[HHE_MAXL];    // q_sp^-1 mod q_j
     u64 qsp_inv_s[HHE_MAXL];
+    u64 qsp_mod[HHE_MAXL];    // q_sp mod q_j (FC leaf sums: galois(c0) enters the sum that is later multiplied by q_sp^-1)
+    u64 qsp_mod_s[HHE_MAXL];
 };
 
 struct AddPlainArgs {

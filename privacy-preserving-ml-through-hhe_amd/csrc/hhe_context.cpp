@@ -308,7 +308,10 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
         return HHE_ERR_DEVICE;
     }
     c->ksc.half = kf.half;
-    for (int j = 0; j < L; ++j) { c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j]; }
+    for (int j = 0; j < L; ++j) {
+        c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j];
+        c->ksc.qsp_mod[j] = qsp % dq[j]; c->ksc.qsp_mod_s[j] = shoup_quot(c->ksc.qsp_mod[j], dq[j]);
+    }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
     if (const char *e = getenv("HHE_LAZY8")) c->lazy8 = atoi(e);
     if (const char *e = getenv("HHE_MERGE")) c->merge_fwd = atoi(e);

@@ -117,6 +117,17 @@ HD U2 ld2_perm(const u64 *base, u32 x_even, int logn, u32 elt)
     return (p0 & 1) ? U2{v.b, v.a} : v;
 }
 
+// (galois(src)[k], galois(src)[k+1]) for even k (GaloisTool::apply_galois as a gather, seal/util/galois.h:32): two 8-byte loads
+HD U2 ld2_galois(const u64 *src, u32 k, int logn, u32 einv, u64 q)
+{
+    const u32 n = 1u << logn;
+    const u32 j0 = (u32)(((u64)k * einv) & (2 * n - 1)), j1 = (u32)((j0 + einv) & (2 * n - 1));
+    U2 v;
+    v.a = (j0 < n) ? src[j0] : negmod(src[j0 - n], q);
+    v.b = (j1 < n) ? src[j1] : negmod(src[j1 - n], q);
+    return v;
+}
+
 // element pair handled by one lane in the load/store phases: (x, lane) and its neighbour in global memory
 template <bool STRIDED> HD void ntt_pair(const NttArgs &a, const NttGeom &g, int e2, int &x, int &lane, int &gi, int &lds0, int &lds1)
 {
@@ -305,7 +316,10 @@ HD StorePre ntt_store_fetch(const NttArgs &a, const NttGeom &g, size_t pbase, in
         else if (a.store_op == STORE_KSF) {
             const size_t bk = g.poly / a.L;  // (item, k)
             p.s = ld2(a.aux_r + bk * g.n + gi);
-            if ((a.base_mask >> (bk & 1)) & 1) p.d = ld2(a.aux_in + (bk >> 1) * a.base_stride + ((bk & 1) * a.L + g.poly % a.L) * g.n + gi);
+            if ((a.base_mask >> (bk & 1)) & 1) {
+                const u64 *bp = a.aux_in + (bk >> 1) * a.base_stride + ((bk & 1) * a.L + g.poly % a.L) * g.n;
+                p.d = a.gal_einv ? ld2_galois(bp, (u32)gi, a.logn, a.gal_einv, a.mods[a.mod_base + g.poly % a.mod_cycle].q) : ld2(bp + gi);
+            }
         }
     } else if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
         const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
@@ -343,6 +357,11 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
                 U2 ac = ld2(ap);
                 ac.a = addmod(ac.a, submod(a.ks.half_mod[j], reduce64(v[0], mj), mj.q), mj.q);
                 ac.b = addmod(ac.b, submod(a.ks.half_mod[j], reduce64(v[1], mj), mj.q), mj.q);
+                if (a.gal_einv && !(g.poly & 1)) {  // k = 0: + q_sp * galois(c0)[j] (the sum is multiplied by q_sp^-1 when it is closed)
+                    const U2 c0 = ld2_galois(a.aux_in + (size_t)(g.poly >> 1) * a.base_stride + (size_t)j * g.n, (u32)gi, a.logn, a.gal_einv, mj.q);
+                    ac.a = addmod(ac.a, shoup_mul(c0.a, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+                    ac.b = addmod(ac.b, shoup_mul(c0.b, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+                }
                 st2(ap, ac);
             }
             return;
@@ -587,6 +606,12 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
         st2(p0, c0); st2(p1, c1);
         return;
     }
+    if (a.S_sp) {
+        u64 *o0 = J == a.K - 1 ? a.S_sp + (b * 2 + 0) * n : a.S + ((b * 2 + 0) * a.L + J) * n;
+        u64 *o1 = J == a.K - 1 ? a.S_sp + (b * 2 + 1) * n : a.S + ((b * 2 + 1) * a.L + J) * n;
+        st2(o0 + i, r0); st2(o1 + i, r1);
+        return;
+    }
     st2(a.S + ((b * 2 + 0) * a.K + J) * n + i, r0);
     st2(a.S + ((b * 2 + 1) * a.K + J) * n + i, r1);
 }
@@ -645,6 +670,12 @@ template <int LL, int MODE> HD void ks_mac_body_t(const KsMacArgs &a, size_t gid
         c0.a = addmod(c0.a, r0.a, m.q); c0.b = addmod(c0.b, r0.b, m.q);
         c1.a = addmod(c1.a, r1.a, m.q); c1.b = addmod(c1.b, r1.b, m.q);
         st2(q0, c0); st2(q1, c1);
+        return;
+    }
+    if (a.S_sp) {
+        u64 *o0 = J == a.K - 1 ? a.S_sp + (b * 2 + 0) * n : a.S + ((b * 2 + 0) * LL + J) * n;
+        u64 *o1 = J == a.K - 1 ? a.S_sp + (b * 2 + 1) * n : a.S + ((b * 2 + 1) * LL + J) * n;
+        st2_stream<4>(o0 + i, r0); st2_stream<4>(o1 + i, r1);
         return;
     }
     st2_stream<4>(a.S + ((b * 2 + 0) * a.K + J) * n + i, r0);
@@ -775,7 +806,6 @@ HD void leaf_sum_body(const LeafSumArgs &a, size_t gid)
     const ModDev &m = a.mods[j];
     u64 v = addmod(a.accS[gid], a.accH[gid], m.q);
     v = shoup_mul(v, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], m.q);
-    if (k == 0) v = addmod(v, a.accG[(b * a.L + j) * n + i], m.q);
     a.out[gid] = addmod(a.out[gid], v, m.q);
 }
 
