@@ -468,7 +468,6 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     // The c0 branch of step i (96 polynomials per 32 items: it cannot fill the 1024 workgroup slots on its own) only feeds
     // the c0 branch of step i+1, and like the digit transforms of step i+1 it depends on nothing later than the inverse
     // transforms of step i: both go into one grid (k_ntt2_fwd).
-    const bool merge = c->merge_fwd != 0;
     // N >= 4096: the row pass of the digit transforms, the key inner product and the inverse row pass run as ONE kernel
     // (ks_row_kernel): T and the sums that are inverse-transformed next never reach memory
     const bool rowk = k_ks_row_supported(c->logn);
@@ -529,8 +528,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             NttArgs a1 = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
             a1.src_item_polys = L; a1.src_item_stride = (size_t)2 * K * n; a1.store_op = STORE_KS1;
             a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = g;
-            if (merge) k_ntt2_inv(a, a1, c->w->stream);
-            else { k_ntt(a, true, c->w->stream); k_ntt(a1, true, c->w->stream); }
+            k_ntt2_inv(a, a1, c->w->stream);
         }
         }
         {   // c0 of the next state in NTT form + permuted-frame product of the current c0
@@ -539,8 +537,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.acc = accp0;
             a.aux_r = c->w->ws_S + (rowk ? (size_t)(i & 1) * K * n : 0);
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g; a.mul_s_off = pdiag_words;
-            if (merge || rowk) { k5 = a; k5_pending = true; }  // launched in the grid of the next step's digit transforms
-            else k_ntt(a, false, c->w->stream);
+            k5 = a; k5_pending = true;  // launched in the grid of the next step's digit transforms
         }
         cur ^= 1;
     }

@@ -313,8 +313,6 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
         c->ksc.qsp_mod[j] = qsp % dq[j]; c->ksc.qsp_mod_s[j] = shoup_quot(c->ksc.qsp_mod[j], dq[j]);
     }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
-    if (const char *e = getenv("HHE_LAZY8")) c->lazy8 = atoi(e);
-    if (const char *e = getenv("HHE_MERGE")) c->merge_fwd = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
     if (const char *e = getenv("HHE_FC_SHARED")) c->fc_shared = atoi(e);
     if (const char *e = getenv("HHE_FC_CHUNK")) c->fc_chunk = (size_t)std::max(0, atoi(e));

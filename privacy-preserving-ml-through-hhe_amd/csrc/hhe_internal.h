@@ -70,8 +70,6 @@ struct hhe_ctx {
     int fc_shared = 1;             // FC rotation trie: children of a node share the digit transforms of its c1 (HHE_FC_SHARED; 2 = force the fallback, tests)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
     size_t fc_chunk = 80;          // items per internal chunk of hhe_fc_row (0 = whole batch); measured 40: 67.1, 80: 64.9, 160: 64.0 ms per MNIST sample
-    int merge_fwd = 1;             // fused matmul: the c0 branch of a step shares the grid of the next step's digit transforms (HHE_MERGE)
-    int lazy8 = 1;                 // forward NTT rounds with one range fold per register round where the moduli allow it (HHE_LAZY8)
     int matmul_mode = 1;           // 1: fused 20-transform pipeline (default), 0: op-by-op schedule
     KsConsts ksc{};
 
@@ -132,7 +130,6 @@ void pasta3_block_randomness(u64 t, u64 nonce, u64 block, u64 *mats, u64 *rcs);
 // the kernels may then fold the butterfly ranges once per register round (NttArgs::lazy8)
 inline int ntt_lazy8(const hhe_ctx *c, int mod_base, int mod_cycle)
 {
-    if (!c->lazy8) return 0;
     for (int i = mod_base; i < mod_base + mod_cycle; ++i) {
         const u64 mv = i < c->K ? c->q[i] : (i <= c->K + c->L ? c->bsk[i - c->K] : c->t);
         if (mv >> 60) return 0;  // SEAL's own primes are at most 60 bits; the BEHZ base has 61

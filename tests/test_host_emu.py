@@ -224,11 +224,10 @@ def test_reference_n65536_29_prime_context_is_accepted(orc, api, emu_lib, mem):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MERGE": "0"}, {"HHE_LAZY8": "0"},
-    {"HHE_MATMUL": "0", "HHE_STREAMS": "1"},
+    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"},
 ])
 def test_every_execution_knob_gives_the_same_words(orc, api, emu_lib, mem, small, monkeypatch, knobs):
-    """chunking / streams / grid merging / range folding / op-by-op schedule only change scheduling"""
+    """chunking / streams / the literal op-by-op schedule only change scheduling"""
     pt = [(3 * i + 1) % 256 for i in range(300)]
     cw, ncw = small.sym_blocks(orc, pt)
     refs = [small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[b, :ncw[b]], b) for b in range(3)]
