@@ -465,11 +465,8 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
         k_galois(ga, c->w->stream);
     }
     int cur = 0;
-    // The c0 branch of step i (96 polynomials per 32 items: it cannot fill the 1024 workgroup slots on its own) only feeds
-    // the c0 branch of step i+1, and like the digit transforms of step i+1 it depends on nothing later than the inverse
-    // transforms of step i: both go into one grid (k_ntt2_fwd).
-    // N >= 4096: the row pass of the digit transforms, the key inner product and the inverse row pass run as ONE kernel
-    // (ks_row_kernel): T and the sums that are inverse-transformed next never reach memory
+    // The c0 branch of step i only feeds the c0 branch of step i+1, and like the digit transforms of step i+1 it depends on
+    // nothing later than the inverse transforms of step i: it is held back (k5) and launched in the grids of step i+1.
     const bool rowk = k_ks_row_supported(c->logn);
     const size_t pdiag_words = (size_t)(PASTA_R + 1) * PASTA_T * ln;  // the Shoup quotients of pdiag follow the table (ensure_block)
     const u64 *key_s = nullptr;
@@ -479,58 +476,60 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     }
     NttArgs k5;
     bool k5_pending = false;
+    // digit transforms of the current d: T[I][J] = NTT_J(d[I] mod q_J)
+    auto digit_args = [&]() {
+        NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
+        a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+        a.store_op = STORE_LAZY;
+        return a;
+    };
+    // N >= 4096 -- four launches per step: strided pass of the digit transforms (+ the held-back c0 branch's strided pass in
+    // the same grid); ks_row_kernel = row pass + key inner product + inverse row pass (+ the c0 branch's row pass as extra
+    // tiles; S_0 alternates between the two halves of ws_S, so that branch reads the previous step's while this step's is
+    // written); strided inverse pass of the special limbs (r_k = INTT(S_k[special]) + floor(q_sp/2)); strided inverse pass
+    // of the c1 limbs with the mod-down epilogue and the Galois map (the next digits' source)
+    auto step_row_kernel = [&](int i, size_t shift) {
+        const NttArgs a = digit_args();
+        if (k5_pending) k_ntt2_fwd_first(k5, a, c->w->stream);
+        else k_ntt_pass(a, false, false, c->w->stream);
+        KsRowArgs x;
+        memset(&x, 0, sizeof(x));
+        x.key = key; x.key_s = key_s; x.S = c->w->ws_S + (size_t)(i & 1) * K * n; x.U1 = scr; x.u_stride = ln; x.Usp = r;
+        x.B = (int)B; x.L = L; x.K = K;
+        x.acc = accp1; x.mul_ptrs = d_pdiag_ptrs; x.mul_shift = shift; x.mul_s_off = pdiag_words;
+        {
+            ProfScope prof(c, *c->w, B);
+            k_ks_row(a, x, k5_pending ? &k5 : nullptr, c->w->stream);
+        }
+        k5_pending = false;
+        NttArgs as = ntt_args(c, r, r, B * 2, K - 1, 1);
+        as.store_op = STORE_RSP;
+        k_ntt_pass(as, true, true, c->w->stream);
+        NttArgs a1 = ntt_args(c, scr, scr, B * L, 0, L);
+        a1.store_op = STORE_KS1; a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = g;
+        k_ntt_pass(a1, true, true, c->w->stream);
+    };
+    // N < 4096 (ragged tiles) -- the same step with the inner product as its own kernel: T and S are materialised
+    auto step_separate = [&](size_t shift) {
+        const NttArgs a = digit_args();
+        KsMacArgs m;
+        memset(&m, 0, sizeof(m));
+        m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
+        m.acc = accp1; m.mul_ptrs = d_pdiag_ptrs; m.mul_shift = shift;  // the I = J digit also feeds the plain product
+        if (k5_pending) { k_ntt2_fwd(k5, a, c->w->stream); k5_pending = false; }
+        else k_ntt(a, false, c->w->stream);
+        k_ks_mac(m, c->w->stream);
+        NttArgs as = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, r, B * 2, K - 1, 1);
+        as.src_item_polys = 1; as.src_item_stride = (size_t)K * n; as.store_op = STORE_RSP;
+        NttArgs a1 = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
+        a1.src_item_polys = L; a1.src_item_stride = (size_t)2 * K * n; a1.store_op = STORE_KS1;
+        a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = g;
+        k_ntt2_inv(as, a1, c->w->stream);
+    };
     for (int i = 0; i < PASTA_T - 1; ++i) {
         const size_t shift = ((size_t)layer * PASTA_T + i) * ln;
-        if (rowk) {
-            NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
-            a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
-            a.store_op = STORE_LAZY;
-            // strided pass of the digit transforms with the c0 branch of the previous step in the same grid; the row pass
-            // of that c0 branch then rides in the grid of ks_row_kernel (S_0 alternates between the two halves of ws_S,
-            // so the c0 branch reads the previous step's while this step's is written)
-            if (k5_pending) k_ntt2_fwd_first(k5, a, c->w->stream);
-            else k_ntt_pass(a, false, false, c->w->stream);
-            KsRowArgs x;
-            memset(&x, 0, sizeof(x));
-            x.key = key; x.key_s = key_s; x.S = c->w->ws_S + (size_t)(i & 1) * K * n; x.U1 = scr; x.u_stride = ln; x.Usp = r; x.B = (int)B; x.L = L; x.K = K;
-            x.acc = accp1; x.mul_ptrs = d_pdiag_ptrs; x.mul_shift = shift; x.mul_s_off = pdiag_words;
-            {
-                ProfScope prof(c, *c->w, B);
-                k_ks_row(a, x, k5_pending ? &k5 : nullptr, c->w->stream);
-            }
-            k5_pending = false;
-            // second (strided) inverse passes: r_k = INTT(S_k[special]) + floor(q_sp/2); c1 of the next state through the
-            // mod-down epilogue and the Galois map
-            NttArgs as = ntt_args(c, r, r, B * 2, K - 1, 1);
-            as.store_op = STORE_RSP;
-            k_ntt_pass(as, true, true, c->w->stream);
-            NttArgs a1 = ntt_args(c, scr, scr, B * L, 0, L);
-            a1.store_op = STORE_KS1; a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = g;
-            k_ntt_pass(a1, true, true, c->w->stream);
-        } else {
-        {   // digits T[I][J] = NTT_J(d[I] mod q_J) and S_k[J] = sum_I T[I][J] * key[I][k][J]; the I = J digit also feeds
-            // the plain product
-            NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
-            a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
-            a.store_op = STORE_LAZY;
-            KsMacArgs m;
-            memset(&m, 0, sizeof(m));
-            m.T = c->w->ws_T; m.key = key; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
-            m.acc = accp1; m.mul_ptrs = d_pdiag_ptrs; m.mul_shift = shift;
-            if (k5_pending) { k_ntt2_fwd(k5, a, c->w->stream); k5_pending = false; }  // c0 branch of the previous step first: its long epilogue overlaps the digit tiles
-            else k_ntt(a, false, c->w->stream);
-            k_ks_mac(m, c->w->stream);
-        }
-        {   // r_k = INTT(S_k[special]) + floor(q_sp/2), then c1 of the next state in coefficient form, already passed
-            // through the Galois map for the next digits (its mod-down epilogue reads r_1)
-            NttArgs a = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, r, B * 2, K - 1, 1);
-            a.src_item_polys = 1; a.src_item_stride = (size_t)K * n; a.store_op = STORE_RSP;
-            NttArgs a1 = ntt_args(c, c->w->ws_S + (size_t)K * n, scr, B * L, 0, L);
-            a1.src_item_polys = L; a1.src_item_stride = (size_t)2 * K * n; a1.store_op = STORE_KS1;
-            a1.aux_r = r; a1.aux_out = c->w->ws_d; a1.gal_elt = g;
-            k_ntt2_inv(a, a1, c->w->stream);
-        }
-        }
+        if (rowk) step_row_kernel(i, shift);
+        else step_separate(shift);
         {   // c0 of the next state in NTT form + permuted-frame product of the current c0
             NttArgs a = ntt_args(c, r, scr2, B * L, 0, L);
             a.src_item_polys = L; a.src_item_stride = 2 * n; a.src_div = L; a.load_op = LOAD_RNEG;
