@@ -368,3 +368,10 @@ def test_generic_key_switch_through_the_row_kernel(orc, api, emu_lib, mem):
     X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
     S.load_keys(X)
     pc.check_ops(X, S, mem, B=2, seed=21)
+
+
+def test_fc_row_variants_full_tiles(orc, api, emu_lib, mem, monkeypatch):
+    """the FC's execution variants at N = 4096 (full tiles): the epilogues that carry the mod-down (STORE_KSF with the
+    Galois-gathered base) and the leaf sums (STORE_RACC with q_sp * galois(c0)) on the tile geometry the GPU runs"""
+    S = Setup(orc, 12, [50] * 3, all_galois=True)
+    pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=emu_lib), S, orc, mem, monkeypatch, n_in=21)
