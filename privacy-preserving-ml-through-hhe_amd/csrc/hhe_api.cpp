@@ -115,15 +115,20 @@ int ensure_key_shoup(hhe_ctx *c, const u64 *key, const u64 **out)
 
 // Evaluator::switch_key_inplace core.  d: item b at d + b*d_stride, [L][N] coefficient form.
 // out[b] = (base ? base polys selected by mask : 0) + key-switched pair.
+// galois_einv > 0 (N >= 4096 only): d and base are the UN-rotated polynomials of a rotation; the digit loads and the base
+// fetch of the fused mod-down read them through the Galois map, so no galois_kernel launch and no rotated copy is needed
 void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, const u64 *base, size_t base_stride,
-                   int base_mask, u64 *out, size_t B)
+                   int base_mask, u64 *out, size_t B, u32 galois_einv = 0)
 {
     const int L = c->L, K = c->K;
     NttArgs a = ntt_args(c, d, c->w->ws_T, B * L * K, 0, K);
     a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = d_stride; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
     a.store_op = STORE_LAZY;  // ks_mac reduces: digits may stay in [0,4q)
+    a.load_einv = galois_einv;
     const u64 *key_s = nullptr;
-    if (k_ks_row_supported(c->logn) && ensure_key_shoup(c, key, &key_s) == HHE_OK) {
+    const bool rowk = k_ks_row_supported(c->logn) && ensure_key_shoup(c, key, &key_s) == HHE_OK;
+    if (galois_einv && !rowk) { fail(HHE_ERR_DEVICE, "switch_key: Shoup table of the key could not be built"); return; }
+    if (rowk) {
         // N >= 4096: strided pass of the digit transforms, then ONE kernel for their row pass, the key inner product and
         // the inverse row pass of all 2K sums (ks_row_kernel, as in the matmul loop), then the strided inverse passes with
         // the mod-down fused into the store of the data limbs -- T and S never make a round trip
@@ -140,7 +145,7 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
         k_ntt_pass(as, true, true, c->w->stream);
         NttArgs ad = ntt_args(c, W, W, B * 2 * L, 0, L);
         ad.store_op = STORE_KSF; ad.aux_r = Usp; ad.aux_in = base; ad.base_stride = base_stride; ad.base_mask = base ? base_mask : 0;
-        ad.aux_out = out;
+        ad.aux_out = out; ad.gal_einv = galois_einv;
         k_ntt_pass(ad, true, true, c->w->stream);
         return;
     }
@@ -161,15 +166,24 @@ int op_apply_galois(hhe_ctx *c, const u64 *ct, u32 elt, u64 *out, size_t B)
     if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     const int L = c->L;
     const size_t n = c->n;
-    GaloisArgs g;
-    memset(&g, 0, sizeof(g));
-    g.mods = c->d_mods; g.logn = c->logn; g.count = (int)(B * L); g.L = L;
-    g.einv = (u32)nt_invmod(elt, 2 * n);
+    const u32 einv = (u32)nt_invmod(elt, 2 * n);
     const u64 *src = ct;
-    if (ct == out) {  // gather cannot run in place
+    if (ct == out) {  // gathers cannot run in place
         rt_d2d(c->w->ws_ct[3], ct, B * c->ct_words() * 8, c->w->stream);
         src = c->w->ws_ct[3];
     }
+    if (k_ks_row_supported(c->logn)) {
+        // N >= 4096: no rotated copies -- the digit loads read c1 and the fused mod-down reads c0 through the Galois map
+        const u64 *key_s = nullptr;
+        int rc = ensure_key_shoup(c, it->second, &key_s);
+        if (rc) return rc;
+        op_switch_key(c, src + L * n, 2 * L * n, it->second, src, 2 * L * n, 1, out, B, einv);
+        return HHE_OK;
+    }
+    GaloisArgs g;
+    memset(&g, 0, sizeof(g));
+    g.mods = c->d_mods; g.logn = c->logn; g.count = (int)(B * L); g.L = L;
+    g.einv = einv;
     // c0' = galois(c0) -> out poly 0 ; d = galois(c1) -> ws_d
     g.in = src; g.in_item_stride = 2 * L * n; g.out = out; g.out_item_stride = 2 * L * n;
     k_galois(g, c->w->stream);

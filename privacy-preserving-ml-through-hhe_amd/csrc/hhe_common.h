@@ -68,6 +68,8 @@ struct NttArgs {
     int src_item_polys;   // polys of one batch item in p-space (0 => whole batch is one item)
     size_t src_item_stride;  // words between items in src
     int load_op, store_op;
+    u32 load_einv;     // first pass: > 0 => the source is read through a Galois map (apply_galois as a gather): elt^-1 mod 2N;
+                       // negation is modulo the SOURCE limb's prime (the digit source d_I lives mod q_I whatever the transform's modulus)
     u32 *zero_flag;    // LOAD_DIGIT: set to 1 when a coefficient equals 0 (the shared-digit FC path then falls back)
     int lazy8;         // every modulus of the launch is below 2^60: forward butterflies correct X once per register round ([0,16q) range)
     int digit_reduce;  // DIGIT: 1 if some q_I >= 4*q_J (else the lazy butterflies absorb the unreduced residue)

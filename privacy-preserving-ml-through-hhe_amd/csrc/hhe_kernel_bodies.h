@@ -128,6 +128,13 @@ HD U2 ld2_galois(const u64 *src, u32 k, int logn, u32 einv, u64 q)
     return v;
 }
 
+// prime of the SOURCE polynomial of poly g.poly in a first pass (digits: limb I of c1, whatever the transform's own modulus)
+HD u64 ntt_src_q(const NttArgs &a, const NttGeom &g)
+{
+    const int ip = a.src_item_polys > 0 ? a.src_item_polys : a.count;
+    return a.mods[(g.poly % ip) / a.src_div].q;
+}
+
 // element pair handled by one lane in the load/store phases: (x, lane) and its neighbour in global memory
 template <bool STRIDED> HD void ntt_pair(const NttArgs &a, const NttGeom &g, int e2, int &x, int &lane, int &gi, int &lds0, int &lds1)
 {
@@ -168,7 +175,8 @@ HD void ntt_load_full(const NttArgs &a, const NttGeom &g, const ModDev &m, const
     for (int k = 0; k < NP; k++) {
         int x, lane, gi;
         ntt_pair<STRIDED>(a, g, tid + k * T, x, lane, gi, l0[k], l1[k]);
-        v[k] = ld2_stream(src + gi);
+        if (FIRST && a.load_einv) v[k] = ld2_galois(src, (u32)gi, a.logn, a.load_einv, ntt_src_q(a, g));
+        else v[k] = ld2_stream(src + gi);
     }
 #pragma unroll
     for (int k = 0; k < NP; k++) {
@@ -195,7 +203,8 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
     for (int e2 = tid; e2 < E2; e2 += T) {
         int x, lane, gi, l0, l1;
         ntt_pair<STRIDED>(a, g, e2, x, lane, gi, l0, l1);
-        const U2 v = ntt_load_op<FIRST>(a, m, g.poly, ld2(src + gi));
+        const U2 raw = (FIRST && a.load_einv) ? ld2_galois(src, (u32)gi, a.logn, a.load_einv, ntt_src_q(a, g)) : ld2(src + gi);
+        const U2 v = ntt_load_op<FIRST>(a, m, g.poly, raw);
         lds[l0] = v.a;
         lds[l1] = v.b;
     }
