@@ -168,6 +168,28 @@ int hhe_pasta3_plain_crypt(hhe_ctx *c, const uint64_t *key_hptr, const uint64_t 
  * sk_hptr: the secret key polynomial at the key level, NTT form [K][N] (SecretKey::data().data()). */
 int hhe_decrypt(hhe_ctx *c, const uint64_t *sk_hptr, const uint64_t *ct_dptr, size_t B, uint64_t *vals_dptr);
 
+/* ---- SEAL 4.0 binary serialization at the boundary: the blobs the reference moves over gRPC and spills to
+ *      disk (src/examples/CSP/CSP.cpp:328-490 `*.load(*context, bytes, size)`, :495-547 spill file = size_t count followed by
+ *      Ciphertext::save streams, :552-605 concatenated stream, protos/hhe.proto:21-24) decoded straight into HBM.
+ *      Layout sources: SEALHeader (seal/serialization.h:60-93), DynArray::save_members (seal/dynarray.h:652-680),
+ *      KSwitchKeys members (seal/kswitchkeys.h:161-178), PublicKey = Ciphertext (seal/publickey.h:89-93); Ciphertext's member
+ *      order is SEAL 4.0.0's as published.  PARITY UNPINNED: the reference holds no serialized SEAL object and libseal is never
+ *      run here, so these are checked by round trips and size arithmetic only.  compr_mode none / zlib / zstd are accepted (the
+ *      latter two through the system's libz.so.1 / libzstd.so.1, looked up at run time); seeded (symmetric-key) objects are
+ *      rejected.  `consumed` returns the size field of the object's header, i.e. where the next object of a stream starts. ---- */
+/* Ciphertext::load: data-level, coefficient-form BFV ciphertext -> out_dptr [size][L][N]; *ct_size = 2 or 3;
+ * parms_id_out (32 bytes, optional) receives the object's parms_id for later saves */
+int hhe_seal_load_ciphertext(hhe_ctx *c, const uint8_t *bytes_hptr, size_t nbytes, uint64_t *out_dptr, size_t out_cap_words,
+                             size_t *ct_size, uint8_t *parms_id_out, size_t *consumed);
+/* Ciphertext::save(stream, compr_mode_type::none) of a device ciphertext; *written = bytes needed (returned also when out_cap is
+ * too small).  parms_id: 32 bytes taken from a loaded object of the same context (SEAL hashes the parameters into it) */
+int hhe_seal_save_ciphertext(hhe_ctx *c, const uint64_t *ct_dptr, size_t ct_size, const uint8_t *parms_id, uint8_t *out_hptr,
+                             size_t out_cap, size_t *written);
+/* RelinKeys::load / GaloisKeys::load: every key of the object is uploaded (relin key(2) into `slot`; Galois keys by element
+ * 2*index+1, seal/galoiskeys.h:48-74) */
+int hhe_seal_load_relin_keys(hhe_ctx *c, int slot, const uint8_t *bytes_hptr, size_t nbytes, size_t *consumed);
+int hhe_seal_load_galois_keys(hhe_ctx *c, const uint8_t *bytes_hptr, size_t nbytes, size_t *consumed, uint32_t *n_keys);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,7 @@ _SYMBOLS = [
     "hhe_pasta3_transcipher", "hhe_pasta3_clear_block_cache", "hhe_mask", "hhe_flatten", "hhe_fc_row", "hhe_decompose",
     "hhe_pasta3_block_randomness", "hhe_pasta3_plain_keystream", "hhe_pasta3_plain_crypt", "hhe_decrypt",
     "hhe_ctx_profile", "hhe_ctx_profile_read", "hhe_relinearize_slot",
+    "hhe_seal_load_ciphertext", "hhe_seal_save_ciphertext", "hhe_seal_load_relin_keys", "hhe_seal_load_galois_keys",
 ]
 
 
@@ -223,6 +224,38 @@ class Context:
         self._chk(self.lib.hhe_fc_row(self.h, _ptr(vi), _ptr(w), C.c_size_t(W), C.c_size_t(n_inputs), C.c_int(relin_slot),
                                       C.c_int(int(default_galois_only)), _ptr(out), C.c_size_t(B)))
 
+
+    # ---- SEAL 4.0 wire format (parity unpinned, see include/hhe_gfx950.h) ----
+    def seal_load_ciphertext(self, blob, out, offset=0):
+        """blob: bytes-like; out: device uint64 buffer.  Returns (ct_size, parms_id bytes, consumed)."""
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))
+        size, used = C.c_size_t(0), C.c_size_t(0)
+        pid = (C.c_uint8 * 32)()
+        self._chk(self.lib.hhe_seal_load_ciphertext(self.h, C.byref(buf, offset), C.c_size_t(len(blob) - offset), _ptr(out),
+                                                    C.c_size_t(out.numel() if hasattr(out, "numel") else out.size),
+                                                    C.byref(size), pid, C.byref(used)))
+        return int(size.value), bytes(pid), int(used.value)
+
+    def seal_save_ciphertext(self, ct, ct_size, parms_id):
+        need = C.c_size_t(0)
+        pid = (C.c_uint8 * 32).from_buffer_copy(parms_id)
+        words = ct_size * self.L * self.n
+        cap = 16 + 32 + 1 + 40 + 16 + 8 + words * 8
+        out = (C.c_uint8 * cap)()
+        self._chk(self.lib.hhe_seal_save_ciphertext(self.h, _ptr(ct), C.c_size_t(ct_size), pid, out, C.c_size_t(cap), C.byref(need)))
+        return bytes(out[:need.value])
+
+    def seal_load_relin_keys(self, blob, slot=0):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))
+        used = C.c_size_t(0)
+        self._chk(self.lib.hhe_seal_load_relin_keys(self.h, C.c_int(slot), buf, C.c_size_t(len(blob)), C.byref(used)))
+        return int(used.value)
+
+    def seal_load_galois_keys(self, blob):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))
+        used, cnt = C.c_size_t(0), C.c_uint32(0)
+        self._chk(self.lib.hhe_seal_load_galois_keys(self.h, buf, C.c_size_t(len(blob)), C.byref(used), C.byref(cnt)))
+        return int(used.value), int(cnt.value)
 
     # ---- client / analyst ends ----
     def plain_keystream(self, key, first_block, nblocks, ks_out):

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libhhe_gfx950.so")
-SOURCES = ["hhe_kernels.hip", "hhe_api.cpp", "hhe_context.cpp", "hhe_pasta_public.cpp", "hhe_client.cpp"]
+SOURCES = ["hhe_kernels.hip", "hhe_api.cpp", "hhe_context.cpp", "hhe_pasta_public.cpp", "hhe_client.cpp", "hhe_seal_wire.cpp"]
 
 
 def needs_build():

@@ -394,3 +394,28 @@ def test_transcipher_unaffected_by_interleaved_eager_work(orc, api, lib, mem, sm
     X.transcipher(mem.to_dev(small.enc_key), cw, ncw, list(range(nb)), again)
     assert (mem.to_host(again) == ref).all()
     assert (ref[0] == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[0, :ncw[0]], 0)).all()
+
+
+def test_seal_streams_in_transcipher_stream_out(orc, api, lib, mem, small):
+    """the CSP's data movement for one request (CSP.cpp:328-490 keys and the HE-encrypted PASTA key arrive as SEAL streams,
+    :552-605 results leave as one): every object crosses the boundary as bytes.  Layout parity unpinned (tests/seal_writer.py);
+    the arithmetic in between is bit-exact against the oracle as everywhere else."""
+    import seal_writer as sw
+    pid_d, pid_k = bytes(range(32)), bytes(range(64, 96))
+    X = api.Context(small.logn, small.q, small.t, lib=lib)
+    X.seal_load_relin_keys(sw.kswitch_keys(pid_k, [small.rk], small.n, X.K, sw.ZSTD))
+    _, cnt = X.seal_load_galois_keys(sw.kswitch_keys(pid_k, sw.galois_table(small.gk), small.n, X.K, sw.ZSTD))
+    assert cnt == len(small.gk.elts)
+    enc_key = mem.empty(small.O.ct_shape)
+    size, pid, _ = X.seal_load_ciphertext(sw.obj(sw.ct_members(pid_d, small.enc_key, 2, small.n, X.L), sw.ZLIB), enc_key)
+    assert size == 2 and (mem.to_host(enc_key) == small.enc_key).all()
+    pt = [(11 * i + 5) % 256 for i in range(200)]
+    cw, ncw = small.sym_blocks(orc, pt)
+    out = mem.empty((2,) + small.O.ct_shape)
+    X.transcipher(enc_key, cw, ncw, np.arange(2), out)
+    stream = b"".join(X.seal_save_ciphertext(out[b], 2, pid) for b in range(2))
+    half = len(stream) // 2
+    for b in range(2):
+        rpid, rsize, rn, rcms, words = sw.parse_ciphertext(stream[b * half:(b + 1) * half])
+        assert (rpid, rsize, rn, rcms) == (pid_d, 2, small.n, X.L)
+        assert (words.reshape(small.O.ct_shape) == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[b, :ncw[b]], b)).all()
