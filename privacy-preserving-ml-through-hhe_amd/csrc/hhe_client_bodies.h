@@ -240,7 +240,7 @@ HD void decrypt_round_body(const DecryptArgs &a, size_t gid)
     mg.q = a.gamma; mg.r_lo = a.g_rlo; mg.r_hi = a.g_rhi;
     Acc128 st = {0, 0}, sg = {0, 0};
     for (int j = 0; j < a.L; j++) {
-        const ModDev &m = a.mods[j];
+        const ModDev m = mod_at(a.mods, j);
         const u64 ph = addmod(a.ct[(b * 2 * a.L + j) * n + i], a.c1s[(b * a.L + j) * n + i], m.q);
         const u64 v = mulmod(ph, a.cj[j], m);
         acc_mac(st, reduce64(v, mt), a.pt[j]);

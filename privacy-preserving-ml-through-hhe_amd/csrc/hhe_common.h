@@ -27,7 +27,27 @@ struct ModDev {
     u64 ninv_t, ninv_t_s;  // N^-1 * t mod q (INTT fused with the BEHZ "times t")
     const u64 *w, *ws;     // psi^bitrev(k), Shoup quotients [N] each (forward rounds: two 8-byte loads keep the 128-VGPR budget spill-free)
     const u64 *iw;         // [N][2]: inverse powers interleaved with their Shoup quotients (inverse rounds: one 16-byte load, measured 3 % faster)
+    u64 nq;                // 2^64 - q.  Read from the table, so the compiler cannot rewrite "+ h * nq" back into "- h * q": the lazy
+                           // product becomes one multiply-add chain and conditional subtractions become add + sign select (no borrow chains)
 };
+
+// The modulus table is written once at context creation.  Kernels read it through the CONSTANT address space: a plain global
+// read of a workgroup-uniform entry cannot be proven unclobbered (the kernels store to global memory), so it compiles to a
+// vector load that is repeated after every barrier and sits in front of every twiddle address as a second dependent memory
+// round trip; from the constant address space it is an s_load into SGPRs (no VGPRs, scalar cache).
+HD ModDev mod_at(const ModDev *mods, int i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) ModDev *p = (const __attribute__((address_space(4))) ModDev *)(mods + i);
+    ModDev m;
+    m.q = p->q; m.r_lo = p->r_lo; m.r_hi = p->r_hi;
+    m.ninv = p->ninv; m.ninv_s = p->ninv_s; m.ninv_t = p->ninv_t; m.ninv_t_s = p->ninv_t_s;
+    m.w = p->w; m.ws = p->ws; m.iw = p->iw; m.nq = p->nq;
+    return m;
+#else
+    return mods[i];
+#endif
+}
 
 // Modulus indices inside ModDev[]: 0..K-1 coefficient primes (K-1 = special),
 // K..K+L Bsk = {B_0..B_{L-1}, m_sk}, K+L+1 = plain modulus t.

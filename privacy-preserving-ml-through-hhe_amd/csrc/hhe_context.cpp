@@ -131,6 +131,7 @@ static void fill_mod(ModDev &md, u64 q, int logn, u64 t, bool with_tables, u64 *
 {
     memset(&md, 0, sizeof(md));
     md.q = q;
+    md.nq = 0 - q;
     const u128 two64 = (u128)1 << 64;
     md.r_hi = (u64)(two64 / q);
     md.r_lo = (u64)(((two64 % q) << 64) / q);

@@ -75,9 +75,29 @@ template <bool STRIDED> HD int ntt_gidx(const NttGeom &g, int x, int lane)
     return (g.tile * g.C + lane) * g.M + x;
 }
 
+// A pointer that was itself loaded from memory (twiddle tables out of ModDev, per-item operand pointers) has no known address
+// space, so its loads compile to flat_load: those count on lgkmcnt as well as vmcnt, every LDS wait behind one becomes a wait
+// for the table load too, and the scheduler may not move them across LDS traffic.  Only a pointer TYPE in the global address
+// space makes them global_load (an assume on is_shared / is_private, or a cast there and back, is folded away).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(1))) u64 *gptr;
+#else
+typedef const u64 *gptr;
+#endif
+HD gptr as_global(const u64 *p) { return (gptr)p; }
 struct alignas(16) U2 { u64 a, b; };
 HD U2 ld2(const u64 *p) { return *reinterpret_cast<const U2 *>(p); }   // 16 B per lane: the coalescing sweet spot
 HD void st2(u64 *p, U2 v) { *reinterpret_cast<U2 *>(p) = v; }
+HD U2 ld2g(gptr p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 w = *(const __attribute__((address_space(1))) u64x2 *)p;
+    return U2{w.x, w.y};
+#else
+    return ld2(p);
+#endif
+}
 // Streaming variants for data that is written once and read by a later kernel / read once.  NTT_NT bits, measured in-call on
 // MI355X (transcipherings/s, default 1): 1 = non-temporal stores of the transform outputs (intermediate, lazy digits T):
 // 229 vs 223 without; 2 = non-temporal transform loads: neutral; 4 = inner-product output S: -1 %; 8 = c0-branch output: neutral;
@@ -132,7 +152,7 @@ HD U2 ld2_galois(const u64 *src, u32 k, int logn, u32 einv, u64 q)
 HD u64 ntt_src_q(const NttArgs &a, const NttGeom &g)
 {
     const int ip = a.src_item_polys > 0 ? a.src_item_polys : a.count;
-    return a.mods[(g.poly % ip) / a.src_div].q;
+    return mod_at(a.mods, (g.poly % ip) / a.src_div).q;
 }
 
 // element pair handled by one lane in the load/store phases: (x, lane) and its neighbour in global memory
@@ -191,7 +211,7 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
     constexpr bool FIRST = (STRIDED != INVERSE);
     const NttGeom g = ntt_geom<CM, CC>(a, bx, by);
-    const ModDev &m = a.mods[g.mod_index];
+    const ModDev m = mod_at(a.mods, g.mod_index);
     const u64 *src;
     if (FIRST) {
         const int ip = a.src_item_polys > 0 ? a.src_item_polys : a.count;
@@ -220,10 +240,9 @@ template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = fa
 HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
     const NttGeom g = ntt_geom<(CC >= 0 ? LOGM : -1), CC>(a, bx, by);
-    const ModDev &m = a.mods[g.mod_index];
-    const u64 q = m.q, q2 = q << 1, q8 = q << 3;
-    const u64 *W = INVERSE ? m.iw : m.w;
-    const u64 *WS = m.ws;
+    const ModDev m = mod_at(a.mods, g.mod_index);
+    const u64 q = m.q, q2 = q << 1, nq = m.nq, nq2 = nq << 1, nq8 = nq << 3;
+    const gptr W = as_global(INVERSE ? m.iw : m.w), WS = as_global(m.ws);
     constexpr int LO_BITS = LOGM - S0 - RHO;
     constexpr int RAD = 1 << RHO;
     const int groups = (g.M >> RHO) * g.C;
@@ -249,9 +268,9 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                     for (int j = 0; j < half; j++) {
                         const int k0 = b * 2 * half + j, k1 = k0 + half;
                         u64 x = v[k0];
-                        if (LAZY8) { if (u == 0) x -= (x >= q8) ? q8 : 0; }
-                        else x -= (x >= q2) ? q2 : 0;
-                        const u64 y = shoup_lazy(v[k1], w, ws, q);
+                        if (LAZY8) { if (u == 0) x = csub(x, nq8); }
+                        else x = csub(x, nq2);
+                        const u64 y = shoup_lazy_n(v[k1], w, ws, nq);
                         v[k0] = x + y;
                         v[k1] = x + q2 - y;
                     }
@@ -271,7 +290,7 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                 const int half = 1 << (RHO - 1 - u);
 #pragma unroll
                 for (int b = 0; b < (1 << u); b++) {
-                    const U2 tw = ld2(W + 2 * (size_t)((tb << u) + b));
+                    const U2 tw = ld2g(W + 2 * (size_t)((tb << u) + b));
                     const u64 w = tw.a, ws = tw.b;
 #pragma unroll
                     for (int j = 0; j < half; j++) {
@@ -281,17 +300,17 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                         if (LAZY8) {
                             int bs = bnd[k0] + bnd[k1];
                             if (bs >= 16) {  // x, y < 8q each
-                                s -= (s >= q8) ? q8 : 0;
+                                s = csub(s, nq8);
                                 bs = 8;
                             }
                             v[k0] = s;
-                            v[k1] = shoup_lazy(x + q * (u64)bnd[k1] - y, w, ws, q);  // + bnd q keeps the difference non-negative
+                            v[k1] = shoup_lazy_n(x + q * (u64)bnd[k1] - y, w, ws, nq);  // + bnd q keeps the difference non-negative
                             bnd[k0] = bs;
                             bnd[k1] = 2;
                         } else {
-                            s -= (s >= q2) ? q2 : 0;
+                            s = csub(s, nq2);
                             v[k0] = s;
-                            v[k1] = shoup_lazy(x + q2 - y, w, ws, q);
+                            v[k1] = shoup_lazy_n(x + q2 - y, w, ws, nq);
                         }
                     }
                 }
@@ -301,7 +320,7 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                 for (int k = 0; k < RAD; k++) {
 #pragma unroll
                     for (int h = 8; h >= 2; h >>= 1)  // fold 16q -> 8q -> 4q -> 2q as far as this value's bound requires
-                        if (bnd[k] > h) { const u64 c = q * (u64)h; v[k] -= (v[k] >= c) ? c : 0; }
+                        if (bnd[k] > h) v[k] = csub(v[k], nq * (u64)h);
                 }
             }
         }
@@ -327,17 +346,17 @@ HD StorePre ntt_store_fetch(const NttArgs &a, const NttGeom &g, size_t pbase, in
             p.s = ld2(a.aux_r + bk * g.n + gi);
             if ((a.base_mask >> (bk & 1)) & 1) {
                 const u64 *bp = a.aux_in + (bk >> 1) * a.base_stride + ((bk & 1) * a.L + g.poly % a.L) * g.n;
-                p.d = a.gal_einv ? ld2_galois(bp, (u32)gi, a.logn, a.gal_einv, a.mods[a.mod_base + g.poly % a.mod_cycle].q) : ld2(bp + gi);
+                p.d = a.gal_einv ? ld2_galois(bp, (u32)gi, a.logn, a.gal_einv, mod_at(a.mods, a.mod_base + g.poly % a.mod_cycle).q) : ld2(bp + gi);
             }
         }
     } else if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
-        const u64 *mp = a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul;
-        p.d = ld2(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);
+        const gptr mp = as_global(a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul);
+        p.d = ld2g(mp + a.mul_shift + (size_t)(g.poly % a.mul_cycle) * g.n + gi);
         if (a.store_op == STORE_MAC) p.acc = ld2(a.acc + pbase + gi);
     } else if (a.store_op == STORE_KS0) {
         const int j = g.poly % a.L;
         const size_t item = g.poly / a.L;
-        p.d = ld2(a.mul_ptrs[item] + a.mul_shift + (size_t)j * g.n + gi);
+        p.d = ld2g(as_global(a.mul_ptrs[item]) + a.mul_shift + (size_t)j * g.n + gi);
         p.s = ld2(a.aux_r + ((item * 2 + 0) * a.K + j) * g.n + gi);
         p.acc = ld2(a.acc + pbase + gi);
         p.gp = ld2_perm(a.aux_in + pbase, (u32)gi, a.logn, a.gal_elt);
@@ -355,13 +374,12 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
     if (INVERSE) {
         const bool st = a.store_op == STORE_SCALE_T;
         for (int k = 0; k < 2; k++) {
-            v[k] = shoup_lazy(v[k], st ? m.ninv_t : m.ninv, st ? m.ninv_t_s : m.ninv_s, q);
-            v[k] -= (v[k] >= q) ? q : 0;
+            v[k] = csub(shoup_lazy_n(v[k], st ? m.ninv_t : m.ninv, st ? m.ninv_t_s : m.ninv_s, m.nq), m.nq);
         }
         if (a.store_op == STORE_RSP || a.store_op == STORE_RACC) { v[0] = addmod(v[0], a.ks.half, q); v[1] = addmod(v[1], a.ks.half, q); }
         if (a.store_op == STORE_RACC) {  // poly = (item, k): rounding terms of a leaf key switch, summed per data limb
             for (int j = 0; j < a.L; j++) {
-                const ModDev &mj = a.mods[j];
+                const ModDev mj = mod_at(a.mods, j);
                 u64 *ap = a.acc + ((size_t)g.poly * a.L + j) * g.n + gi;
                 U2 ac = ld2(ap);
                 ac.a = addmod(ac.a, submod(a.ks.half_mod[j], reduce64(v[0], mj), mj.q), mj.q);
@@ -408,12 +426,8 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
         // forward results arrive in [0,4q), or [0,16q) from LAZY8 rounds; a Barrett product takes them as they are
         if (a.store_op != STORE_MUL && a.store_op != STORE_MAC)
             for (int k = 0; k < 2; k++) {
-                if (a.lazy8) {
-                    v[k] -= (v[k] >= (q << 3)) ? (q << 3) : 0;
-                    v[k] -= (v[k] >= (q << 2)) ? (q << 2) : 0;
-                }
-                v[k] -= (v[k] >= q2) ? q2 : 0;
-                v[k] -= (v[k] >= q) ? q : 0;
+                if (a.lazy8) v[k] = csub(csub(v[k], m.nq << 3), m.nq << 2);
+                v[k] = csub(csub(v[k], m.nq << 1), m.nq);
             }
         if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
             const U2 d = pre.d;
@@ -432,9 +446,9 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             U2 acc = pre.acc;
             const u64 g0 = pre.gp.a, g1 = pre.gp.b;
             if (a.mul_s_off) {  // plaintext diagonal with its Shoup quotient: a lazy product in [0,2q) instead of a Barrett product
-                const U2 ds = ld2(a.mul_ptrs[g.poly / a.L] + a.mul_shift + a.mul_s_off + (size_t)j * g.n + gi);
-                acc.a += shoup_lazy(g0, d.a, ds.a, q); acc.a -= (acc.a >= q2) ? q2 : 0; acc.a -= (acc.a >= q) ? q : 0;
-                acc.b += shoup_lazy(g1, d.b, ds.b, q); acc.b -= (acc.b >= q2) ? q2 : 0; acc.b -= (acc.b >= q) ? q : 0;
+                const U2 ds = ld2g(as_global(a.mul_ptrs[g.poly / a.L]) + a.mul_shift + a.mul_s_off + (size_t)j * g.n + gi);
+                acc.a = csub(csub(acc.a + shoup_lazy_n(g0, d.a, ds.a, m.nq), m.nq << 1), m.nq);
+                acc.b = csub(csub(acc.b + shoup_lazy_n(g1, d.b, ds.b, m.nq), m.nq << 1), m.nq);
             } else {
                 acc.a = addmod(acc.a, mulmod(g0, d.a, m), q);
                 acc.b = addmod(acc.b, mulmod(g1, d.b, m), q);
@@ -477,7 +491,7 @@ template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1, int T = NTT_THRE
 HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds)
 {
     const NttGeom g = ntt_geom<CM, CC>(a, bx, by);
-    const ModDev &m = a.mods[g.mod_index];
+    const ModDev m = mod_at(a.mods, g.mod_index);
     u64 *dst = a.dst + (size_t)g.poly * g.n;
     const size_t pbase = (size_t)g.poly * g.n;
     const int E2 = (g.M * g.C) >> 1;
@@ -499,7 +513,7 @@ HD void elt_body(const EltArgs &a, int op, size_t gid)
     const size_t p = gid >> a.logn;
     if (p >= (size_t)a.count) return;
     const size_t i = gid & (n - 1);
-    const ModDev &m = a.mods[a.mod_base + (int)(p % a.mod_cycle)];
+    const ModDev m = mod_at(a.mods, a.mod_base + (int)(p % a.mod_cycle));
     const size_t bp = a.b_cycle ? p % a.b_cycle : p;
     const u64 x = op == ELT_BCAST ? 0 : a.a[gid];
     if (op == ELT_SHOUP) { a.out[gid] = shoup_quotient(x, m); return; }
@@ -534,7 +548,7 @@ HD void galois_body(const GaloisArgs &a, size_t gid)
     if (p >= (size_t)a.count) return;
     const u32 k = (u32)(gid & ((n >> 1) - 1)) << 1;
     const size_t item = p / a.L, limb = p % a.L;
-    const u64 q = a.mods[limb].q;
+    const u64 q = mod_at(a.mods, limb).q;
     const u64 *src = a.in + item * a.in_item_stride + limb * n;
     const u32 j0 = (u32)(((u64)k * a.einv) & (2 * n - 1)), j1 = (u32)((j0 + a.einv) & (2 * n - 1));
     U2 v;
@@ -557,7 +571,7 @@ HD void perm_body(const PermArgs &a, size_t gid)
     if (p >= (size_t)a.count) return;
     const u32 x = (u32)(gid & (n - 1));
     const size_t item = p / a.L, j = p % a.L;
-    const ModDev &m = a.mods[j];
+    const ModDev m = mod_at(a.mods, j);
     const u64 v = a.in[p * n + ntt_perm_index(x, a.logn, a.elt)];
     u64 *o = a.out + item * a.out_item_stride + j * n + x;
     if (a.mac) *o = addmod(*o, mulmod(v, a.mul_ptrs[item][a.mul_shift + j * n + x], m), m.q);
@@ -573,7 +587,7 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
     const int J = (int)(bj % a.K);
     const size_t b = bj / a.K;
     if (b >= (size_t)a.B) return;
-    const ModDev &m = a.mods[J];
+    const ModDev m = mod_at(a.mods, J);
     Acc128 s0[2] = {{0, 0}, {0, 0}}, s1[2] = {{0, 0}, {0, 0}};
     u32 p0 = (u32)i;
     if (a.perm_elt) p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt);
@@ -584,7 +598,7 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
         const U2 k0 = ld2(a.key + (((size_t)I * 2 + 0) * a.K + J) * n + i);
         const U2 k1 = ld2(a.key + (((size_t)I * 2 + 1) * a.K + J) * n + i);
         if (a.acc && I == J) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product
-            const U2 d = ld2(a.mul_ptrs[b] + a.mul_shift + (size_t)J * n + i);
+            const U2 d = ld2g(as_global(a.mul_ptrs[b]) + a.mul_shift + (size_t)J * n + i);
             u64 *ap = a.acc + (b * a.L + J) * n + i;
             U2 acc = ld2(ap);
             acc.a = addmod(acc.a, mulmod(t.a, d.a, m), m.q);
@@ -640,7 +654,7 @@ template <int LL, int MODE> HD void ks_mac_body_t(const KsMacArgs &a, size_t gid
     const size_t b = bj / a.K;
     if (b >= (size_t)a.B) return;
     ModDev m;  // the three words the Barrett reductions need, fetched with the first wave of loads
-    m.q = a.mods[J].q; m.r_lo = a.mods[J].r_lo; m.r_hi = a.mods[J].r_hi;
+    m.q = mod_at(a.mods, J).q; m.r_lo = mod_at(a.mods, J).r_lo; m.r_hi = mod_at(a.mods, J).r_hi;
     constexpr bool PERM = MODE == KS_PERM || MODE == KS_LEAF;
     u32 p0 = (u32)i;
     if (PERM) p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt);
@@ -706,7 +720,7 @@ HD void ks_corr_body(const KsCorrArgs &a, size_t gid)
     if (gid >= (size_t)2 * a.K * n) return;
     const size_t x = gid & (n - 1);
     const int J = (int)((gid >> a.logn) % a.K), k = (int)(gid >> a.logn) / a.K;
-    const ModDev &m = a.mods[J];
+    const ModDev m = mod_at(a.mods, J);
     u64 sum = 0;
     for (int I = 0; I < a.L; I++)
         if (I != J) sum = addmod(sum, mulmod(a.key[(((size_t)I * 2 + k) * a.K + J) * n + x], a.qmod[I * a.K + J], m), m.q);
@@ -730,11 +744,11 @@ template <int CM, int CC>
 HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, int J, int I, int tid, const u64 *lds, u64 *acc0, u64 *acc1)
 {
     const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
-    const ModDev &m = fa.mods[J];
-    const u64 q = m.q, q2 = q << 1, q4 = q << 2;
+    const ModDev m = mod_at(fa.mods, J);
+    const u64 q = m.q, nq = m.nq, nq2 = nq << 1, nq4 = nq << 2;
     const size_t kofs = (((size_t)I * 2) * x.K + J) * g.n, kstep = (size_t)x.K * g.n;
     const bool diag = x.acc && I == J;
-    const u64 *dptr = diag ? x.mul_ptrs[b] + x.mul_shift + (size_t)J * g.n : nullptr;
+    const gptr dptr = diag ? as_global(x.mul_ptrs[b]) + x.mul_shift + (size_t)J * g.n : as_global(nullptr);
     u64 *ap = diag ? x.acc + ((size_t)b * x.L + J) * g.n : nullptr;
 #pragma unroll
     for (int k = 0; k < KSROW_NP; k++) {
@@ -743,25 +757,25 @@ HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, i
         const U2 k0 = ld2(x.key + kofs + gi), k0s = ld2(x.key_s + kofs + gi);
         const U2 k1 = ld2(x.key + kofs + kstep + gi), k1s = ld2(x.key_s + kofs + kstep + gi);
         const u64 v0 = lds[l0], v1 = lds[l1];
-        acc0[2 * k] += shoup_lazy(v0, k0.a, k0s.a, q);
-        acc0[2 * k + 1] += shoup_lazy(v1, k0.b, k0s.b, q);
-        acc1[2 * k] += shoup_lazy(v0, k1.a, k1s.a, q);
-        acc1[2 * k + 1] += shoup_lazy(v1, k1.b, k1s.b, q);
+        acc0[2 * k] += shoup_lazy_n(v0, k0.a, k0s.a, nq);
+        acc0[2 * k + 1] += shoup_lazy_n(v1, k0.b, k0s.b, nq);
+        acc1[2 * k] += shoup_lazy_n(v0, k1.a, k1s.a, nq);
+        acc1[2 * k + 1] += shoup_lazy_n(v1, k1.b, k1s.b, nq);
         if ((I & 3) == 3) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
                 u64 &a0 = acc0[2 * k + e], &a1 = acc1[2 * k + e];
-                a0 -= (a0 >= q4) ? q4 : 0; a0 -= (a0 >= q2) ? q2 : 0;
-                a1 -= (a1 >= q4) ? q4 : 0; a1 -= (a1 >= q2) ? q2 : 0;
+                a0 = csub(csub(a0, nq4), nq2);
+                a1 = csub(csub(a1, nq4), nq2);
             }
         }
         if (diag) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product (lazy input)
-            const U2 d = ld2(dptr + gi);
+            const U2 d = ld2g(dptr + gi);
             U2 ac = ld2(ap + gi);
             if (x.mul_s_off) {  // Shoup product with the table's quotients
-                const U2 ds = ld2(dptr + x.mul_s_off + gi);
-                ac.a += shoup_lazy(v0, d.a, ds.a, q); ac.a -= (ac.a >= q2) ? q2 : 0; ac.a -= (ac.a >= q) ? q : 0;
-                ac.b += shoup_lazy(v1, d.b, ds.b, q); ac.b -= (ac.b >= q2) ? q2 : 0; ac.b -= (ac.b >= q) ? q : 0;
+                const U2 ds = ld2g(dptr + x.mul_s_off + gi);
+                ac.a = csub(csub(ac.a + shoup_lazy_n(v0, d.a, ds.a, nq), nq2), nq);
+                ac.b = csub(csub(ac.b + shoup_lazy_n(v1, d.b, ds.b, nq), nq2), nq);
             } else {
                 ac.a = addmod(ac.a, mulmod(v0, d.a, m), q);
                 ac.b = addmod(ac.b, mulmod(v1, d.b, m), q);
@@ -775,16 +789,16 @@ template <int CM, int CC>
 HD void ks_row_flush_phase(const NttArgs &fa, int bx, int J, int tid, u64 *lds, const u64 *acc, u64 *canon_out)
 {
     const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
-    const u64 q = fa.mods[J].q, q2 = q << 1, q4 = q << 2;
+    const u64 nq = mod_at(fa.mods, J).nq, nq2 = nq << 1, nq4 = nq << 2;
 #pragma unroll
     for (int k = 0; k < KSROW_NP; k++) {
         int xx, lane, gi, l0, l1;
         ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
         u64 v0 = acc[2 * k], v1 = acc[2 * k + 1];
-        v0 -= (v0 >= q4) ? q4 : 0; v0 -= (v0 >= q2) ? q2 : 0;
-        v1 -= (v1 >= q4) ? q4 : 0; v1 -= (v1 >= q2) ? q2 : 0;
+        v0 = csub(csub(v0, nq4), nq2);
+        v1 = csub(csub(v1, nq4), nq2);
         if (canon_out) {
-            v0 -= (v0 >= q) ? q : 0; v1 -= (v1 >= q) ? q : 0;
+            v0 = csub(v0, nq); v1 = csub(v1, nq);
             st2(canon_out + gi, U2{v0, v1});
         } else { lds[l0] = v0; lds[l1] = v1; }
     }
@@ -812,7 +826,7 @@ HD void leaf_sum_body(const LeafSumArgs &a, size_t gid)
     const int k = (int)(r & 1);
     const size_t b = r >> 1;
     if (b >= (size_t)a.B) return;
-    const ModDev &m = a.mods[j];
+    const ModDev m = mod_at(a.mods, j);
     u64 v = addmod(a.accS[gid], a.accH[gid], m.q);
     v = shoup_mul(v, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], m.q);
     a.out[gid] = addmod(a.out[gid], v, m.q);
@@ -828,8 +842,8 @@ HD void ks_finish_body(const KsFinishArgs &a, size_t gid)
     const int k = (int)(r & 1);
     const size_t b = r >> 1;
     if (b >= (size_t)a.B) return;
-    const ModDev &m = a.mods[j];
-    const u64 qsp = a.mods[a.K - 1].q;
+    const ModDev m = mod_at(a.mods, j);
+    const u64 qsp = mod_at(a.mods, a.K - 1).q;
     const u64 sp = a.S[((b * 2 + k) * a.K + (a.K - 1)) * n + i];
     const u64 rk = addmod(sp, a.half, qsp);
     const u64 rj = reduce64(rk, m);
@@ -856,7 +870,7 @@ HD void add_plain_body(const AddPlainArgs &a, size_t gid)
     u64 rem = lo - fix * a.t;
     while (rem >= a.t) { rem -= a.t; fix++; }
     for (int j = 0; j < a.L; j++) {
-        const ModDev &m = a.mods[j];
+        const ModDev m = mod_at(a.mods, j);
         Acc128 s = {0, 0};
         acc_mac(s, mval, a.delta[j]);
         acc_add(s, fix);
@@ -932,7 +946,7 @@ HD void behz_extend_body(const BehzExtendArgs &a, size_t gid)
     u64 tmp[HHE_MAXL];
     u64 ymt = 0;
     for (int l = 0; l < L; l++) {
-        const ModDev &m = a.mods[l];
+        const ModDev m = mod_at(a.mods, l);
         u64 v = mulmod(a.x[(p * L + l) * n + i], z.mt_mod_q[l], m);
         v = shoup_mul(v, z.inv_punct_q[l], z.inv_punct_q_s[l], m.q);
         tmp[l] = v;
@@ -941,7 +955,7 @@ HD void behz_extend_body(const BehzExtendArgs &a, size_t gid)
     ymt &= MTm;
     const u64 r = (ymt * z.neg_inv_q_mt) & MTm;
     for (int pb = 0; pb <= L; pb++) {
-        const ModDev &mp = a.mods[a.K + pb];
+        const ModDev mp = mod_at(a.mods, a.K + pb);
         Acc128 s = {0, 0};
         for (int l = 0; l < L; l++) {
             acc_mac(s, tmp[l], z.punct_q_bsk[l][pb]);
@@ -963,7 +977,7 @@ HD void tensor_body(const TensorArgs &a, size_t gid)
     const int j = (int)(r % a.limbs);
     const size_t b = r / a.limbs;
     if (b >= (size_t)a.B) return;
-    const ModDev &m = a.mods[a.mod_base + j];
+    const ModDev m = mod_at(a.mods, a.mod_base + j);
     const size_t lim = a.limbs;
     const u64 a0 = a.a[((b * 2 + 0) * lim + j) * n + i], a1 = a.a[((b * 2 + 1) * lim + j) * n + i];
     const u64 b0 = a.b[((b * 2 + 0) * lim + j) * n + i], b1 = a.b[((b * 2 + 1) * lim + j) * n + i];
@@ -986,9 +1000,9 @@ HD void behz_floor_body(const BehzFloorArgs &a, size_t gid)
     const int L = a.L;
     u64 tq[HHE_MAXL], f[HHE_MAXL + 1], tb[HHE_MAXL];
     for (int l = 0; l < L; l++)
-        tq[l] = shoup_mul(a.dq[(p * L + l) * n + i], z.inv_punct_q[l], z.inv_punct_q_s[l], a.mods[l].q);
+        tq[l] = shoup_mul(a.dq[(p * L + l) * n + i], z.inv_punct_q[l], z.inv_punct_q_s[l], mod_at(a.mods, l).q);
     for (int pb = 0; pb <= L; pb++) {
-        const ModDev &mp = a.mods[a.K + pb];
+        const ModDev mp = mod_at(a.mods, a.K + pb);
         Acc128 s = {0, 0};
         for (int l = 0; l < L; l++) {
             acc_mac(s, tq[l], z.punct_q_bsk[l][pb]);
@@ -998,8 +1012,8 @@ HD void behz_floor_body(const BehzFloorArgs &a, size_t gid)
         const u64 x = a.db[(p * (L + 1) + pb) * n + i];
         f[pb] = mulmod(addmod(x, mp.q - conv, mp.q), z.inv_q_bsk[pb], mp);
     }
-    for (int l = 0; l < L; l++) tb[l] = mulmod(f[l], z.inv_punct_B[l], a.mods[a.K + l]);
-    const ModDev &ms = a.mods[a.K + L];
+    for (int l = 0; l < L; l++) tb[l] = mulmod(f[l], z.inv_punct_B[l], mod_at(a.mods, a.K + l));
+    const ModDev ms = mod_at(a.mods, a.K + L);
     Acc128 s = {0, 0};
     for (int l = 0; l < L; l++) {
         acc_mac(s, tb[l], z.punct_B_msk[l]);
@@ -1009,7 +1023,7 @@ HD void behz_floor_body(const BehzFloorArgs &a, size_t gid)
     const u64 alpha = mulmod(addmod(conv, ms.q - f[L], ms.q), z.inv_B_msk, ms);
     const bool negative = alpha > (z.msk >> 1);
     for (int j = 0; j < L; j++) {
-        const ModDev &m = a.mods[j];
+        const ModDev m = mod_at(a.mods, j);
         Acc128 t = {0, 0};
         for (int l = 0; l < L; l++) {
             acc_mac(t, tb[l], z.punct_B_q[l][j]);

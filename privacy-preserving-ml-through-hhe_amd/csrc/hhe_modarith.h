@@ -15,6 +15,15 @@ HD u64 mulhi64(u64 a, u64 b)
 
 // x*w mod q in [0,2q) for any x < 2^64, with ws = floor(w * 2^64 / q), w < q.
 HD u64 shoup_lazy(u64 x, u64 w, u64 ws, u64 q) { return x * w - mulhi64(x, ws) * q; }
+// the same value computed as x*w + hi*(2^64 - q): with nq taken from ModDev (opaque to the compiler) this is a v_mad_u64_u32
+// chain that can absorb one more 64-bit addend, instead of two products and a v_sub_co / v_subb_co pair
+HD u64 shoup_lazy_n(u64 x, u64 w, u64 ws, u64 nq) { return x * w + mulhi64(x, ws) * nq; }
+// x >= c ? x - c : x given nc = 2^64 - c, for c <= 2^63 and x < 2c: one 64-bit add and a select on the sign of the sum
+HD u64 csub(u64 x, u64 nc)
+{
+    const u64 t = x + nc;
+    return (long long)t < 0 ? x : t;
+}
 HD u64 shoup_mul(u64 x, u64 w, u64 ws, u64 q)
 {
     u64 r = shoup_lazy(x, w, ws, q);
