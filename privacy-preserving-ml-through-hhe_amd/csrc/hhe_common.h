@@ -26,6 +26,8 @@ struct ModDev {
     u64 ninv, ninv_s;      // N^-1 mod q and its Shoup quotient
     u64 ninv_t, ninv_t_s;  // N^-1 * t mod q (INTT fused with the BEHZ "times t")
     const u64 *w, *ws;     // psi^bitrev(k), Shoup quotients [N] each (forward rounds: two 8-byte loads keep the 128-VGPR budget spill-free)
+    const u64 *fw;         // [N][2]: the forward powers interleaved with their quotients as well (the row kernel's 8-points-per-lane rounds have the
+                           // registers for one 16-byte load per twiddle; half the vector-memory instructions of w / ws)
     const u64 *iw;         // [N][2]: inverse powers interleaved with their Shoup quotients (inverse rounds: one 16-byte load, measured 3 % faster)
     u64 nq;                // 2^64 - q.  Read from the table, so the compiler cannot rewrite "+ h * nq" back into "- h * q": the lazy
                            // product becomes one multiply-add chain and conditional subtractions become add + sign select (no borrow chains)
@@ -42,11 +44,21 @@ HD ModDev mod_at(const ModDev *mods, int i)
     ModDev m;
     m.q = p->q; m.r_lo = p->r_lo; m.r_hi = p->r_hi;
     m.ninv = p->ninv; m.ninv_s = p->ninv_s; m.ninv_t = p->ninv_t; m.ninv_t_s = p->ninv_t_s;
-    m.w = p->w; m.ws = p->ws; m.iw = p->iw; m.nq = p->nq;
+    m.w = p->w; m.ws = p->ws; m.fw = p->fw; m.iw = p->iw; m.nq = p->nq;
     return m;
 #else
     return mods[i];
 #endif
+}
+
+// the same for an index that is uniform over the workgroup (every transform kernel: one modulus per tile): stating the
+// uniformity keeps the entry in SGPRs even where the compiler's divergence analysis gives up (inside the strided lane loops)
+HD ModDev mod_at_u(const ModDev *mods, int i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    i = __builtin_amdgcn_readfirstlane(i);
+#endif
+    return mod_at(mods, i);
 }
 
 // Modulus indices inside ModDev[]: 0..K-1 coefficient primes (K-1 = special),

@@ -139,11 +139,12 @@ static void fill_mod(ModDev &md, u64 q, int logn, u64 t, bool with_tables, u64 *
     const size_t n = (size_t)1 << logn;
     const u64 psi = nt_minimal_primitive_root(2 * n, q), ipsi = nt_invmod(psi, q);
     if (root_out) *root_out = psi;
-    u64 *w = host_tab, *ws = host_tab + n, *iw = host_tab + 2 * n;
+    u64 *w = host_tab, *ws = host_tab + n, *iw = host_tab + 2 * n, *fw = host_tab + 4 * n;
     u64 pw = 1, ipw = 1;
     for (size_t k = 0; k < n; ++k) {
         const size_t r = bit_reverse(k, logn);
         w[r] = pw; ws[r] = shoup_quot(pw, q);
+        fw[2 * r] = w[r]; fw[2 * r + 1] = ws[r];
         iw[2 * r] = ipw; iw[2 * r + 1] = shoup_quot(ipw, q);
         pw = nt_mulmod(pw, psi, q);
         ipw = nt_mulmod(ipw, ipsi, q);
@@ -152,7 +153,7 @@ static void fill_mod(ModDev &md, u64 q, int logn, u64 t, bool with_tables, u64 *
     md.ninv_s = shoup_quot(md.ninv, q);
     md.ninv_t = nt_mulmod(md.ninv, t % q, q);
     md.ninv_t_s = shoup_quot(md.ninv_t, q);
-    md.w = dev_tab; md.ws = dev_tab + n; md.iw = dev_tab + 2 * n;
+    md.w = dev_tab; md.ws = dev_tab + n; md.iw = dev_tab + 2 * n; md.fw = dev_tab + 4 * n;
 }
 
 // CoeffModulus::BFVDefault(N) (seal/coeffmodulus via util/globals.cpp, SEAL 4.0.0) as used by
@@ -227,12 +228,12 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     allq.insert(allq.end(), c->bsk.begin(), c->bsk.end());
     allq.push_back(t);
     std::vector<ModDev> mods(c->nmod);
-    std::vector<u64> host_tab((size_t)c->nmod * 4 * n);
+    std::vector<u64> host_tab((size_t)c->nmod * 6 * n);
     c->d_tables = (u64 *)rt_malloc(host_tab.size() * 8);
     c->d_mods = (ModDev *)rt_malloc(sizeof(ModDev) * c->nmod);
     c->roots.resize(K);
     for (int i = 0; i < c->nmod; ++i)
-        fill_mod(mods[i], allq[i], logn, t, true, host_tab.data() + (size_t)i * 4 * n, c->d_tables + (size_t)i * 4 * n,
+        fill_mod(mods[i], allq[i], logn, t, true, host_tab.data() + (size_t)i * 6 * n, c->d_tables + (size_t)i * 6 * n,
                  i < K ? &c->roots[i] : nullptr);
     // BatchEncoder matrix_reps_index_map
     c->slot_map.resize(n);

@@ -211,7 +211,7 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
     constexpr bool FIRST = (STRIDED != INVERSE);
     const NttGeom g = ntt_geom<CM, CC>(a, bx, by);
-    const ModDev m = mod_at(a.mods, g.mod_index);
+    const ModDev m = mod_at_u(a.mods, g.mod_index);
     const u64 *src;
     if (FIRST) {
         const int ip = a.src_item_polys > 0 ? a.src_item_polys : a.count;
@@ -236,13 +236,13 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 // invariant).  LAZY8 (all moduli of the launch < 2^60, i.e. 16q <= 2^64): fold once per round instead -- X >= 8q ? X - 8q
 // at the round's first stage, then up to four stages grow it to < 16q, which still fits 64 bits.  Saves RHO-1 of every RHO
 // conditional subtractions; the values stay congruent, so every fully reduced result is unchanged.
-template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS>
+template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS, bool FW16 = false>
 HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 {
     const NttGeom g = ntt_geom<(CC >= 0 ? LOGM : -1), CC>(a, bx, by);
-    const ModDev m = mod_at(a.mods, g.mod_index);
+    const ModDev m = mod_at_u(a.mods, g.mod_index);
     const u64 q = m.q, q2 = q << 1, nq = m.nq, nq2 = nq << 1, nq8 = nq << 3;
-    const gptr W = as_global(INVERSE ? m.iw : m.w), WS = as_global(m.ws);
+    const gptr W = as_global(INVERSE ? m.iw : FW16 ? m.fw : m.w), WS = as_global(m.ws);
     constexpr int LO_BITS = LOGM - S0 - RHO;
     constexpr int RAD = 1 << RHO;
     const int groups = (g.M >> RHO) * g.C;
@@ -263,7 +263,9 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                 const int half = 1 << (RHO - 1 - u);
 #pragma unroll
                 for (int b = 0; b < (1 << u); b++) {
-                    const u64 w = W[(tb << u) + b], ws = WS[(tb << u) + b];
+                    u64 w, ws;
+                    if (FW16) { const U2 tw = ld2g(W + 2 * (size_t)((tb << u) + b)); w = tw.a; ws = tw.b; }
+                    else { w = W[(tb << u) + b]; ws = WS[(tb << u) + b]; }
 #pragma unroll
                     for (int j = 0; j < half; j++) {
                         const int k0 = b * 2 * half + j, k1 = k0 + half;
@@ -491,7 +493,7 @@ template <bool STRIDED, bool INVERSE, int CM = -1, int CC = -1, int T = NTT_THRE
 HD void ntt_body_store(const NttArgs &a, int bx, int by, int tid, const u64 *lds)
 {
     const NttGeom g = ntt_geom<CM, CC>(a, bx, by);
-    const ModDev m = mod_at(a.mods, g.mod_index);
+    const ModDev m = mod_at_u(a.mods, g.mod_index);
     u64 *dst = a.dst + (size_t)g.poly * g.n;
     const size_t pbase = (size_t)g.poly * g.n;
     const int E2 = (g.M * g.C) >> 1;
@@ -587,7 +589,7 @@ HD void ks_mac_body(const KsMacArgs &a, size_t gid)
     const int J = (int)(bj % a.K);
     const size_t b = bj / a.K;
     if (b >= (size_t)a.B) return;
-    const ModDev m = mod_at(a.mods, J);
+    const ModDev m = mod_at_u(a.mods, J);
     Acc128 s0[2] = {{0, 0}, {0, 0}}, s1[2] = {{0, 0}, {0, 0}};
     u32 p0 = (u32)i;
     if (a.perm_elt) p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt);
@@ -654,7 +656,7 @@ template <int LL, int MODE> HD void ks_mac_body_t(const KsMacArgs &a, size_t gid
     const size_t b = bj / a.K;
     if (b >= (size_t)a.B) return;
     ModDev m;  // the three words the Barrett reductions need, fetched with the first wave of loads
-    m.q = mod_at(a.mods, J).q; m.r_lo = mod_at(a.mods, J).r_lo; m.r_hi = mod_at(a.mods, J).r_hi;
+    m.q = mod_at_u(a.mods, J).q; m.r_lo = mod_at_u(a.mods, J).r_lo; m.r_hi = mod_at_u(a.mods, J).r_hi;
     constexpr bool PERM = MODE == KS_PERM || MODE == KS_LEAF;
     u32 p0 = (u32)i;
     if (PERM) p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt);
@@ -720,7 +722,7 @@ HD void ks_corr_body(const KsCorrArgs &a, size_t gid)
     if (gid >= (size_t)2 * a.K * n) return;
     const size_t x = gid & (n - 1);
     const int J = (int)((gid >> a.logn) % a.K), k = (int)(gid >> a.logn) / a.K;
-    const ModDev m = mod_at(a.mods, J);
+    const ModDev m = mod_at_u(a.mods, J);
     u64 sum = 0;
     for (int I = 0; I < a.L; I++)
         if (I != J) sum = addmod(sum, mulmod(a.key[(((size_t)I * 2 + k) * a.K + J) * n + x], a.qmod[I * a.K + J], m), m.q);
@@ -744,7 +746,7 @@ template <int CM, int CC>
 HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, int J, int I, int tid, const u64 *lds, u64 *acc0, u64 *acc1)
 {
     const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
-    const ModDev m = mod_at(fa.mods, J);
+    const ModDev m = mod_at_u(fa.mods, J);
     const u64 q = m.q, nq = m.nq, nq2 = nq << 1, nq4 = nq << 2;
     const size_t kofs = (((size_t)I * 2) * x.K + J) * g.n, kstep = (size_t)x.K * g.n;
     const bool diag = x.acc && I == J;
@@ -789,7 +791,7 @@ template <int CM, int CC>
 HD void ks_row_flush_phase(const NttArgs &fa, int bx, int J, int tid, u64 *lds, const u64 *acc, u64 *canon_out)
 {
     const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
-    const u64 nq = mod_at(fa.mods, J).nq, nq2 = nq << 1, nq4 = nq << 2;
+    const u64 nq = mod_at_u(fa.mods, J).nq, nq2 = nq << 1, nq4 = nq << 2;
 #pragma unroll
     for (int k = 0; k < KSROW_NP; k++) {
         int xx, lane, gi, l0, l1;

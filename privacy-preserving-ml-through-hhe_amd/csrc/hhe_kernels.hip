@@ -81,7 +81,7 @@ struct NttRounds {
     {
         if constexpr (I < R) {
             constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T>(a, bx, by, threadIdx.x, lds);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512>(a, bx, by, threadIdx.x, lds);
             __syncthreads();
             fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
         }

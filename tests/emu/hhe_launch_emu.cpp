@@ -36,7 +36,7 @@ static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
 {
     if constexpr (I < NttSched<LOGM, SCH>::R) {
         constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T>(a, bx, by, t, lds);
+        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512>(a, bx, by, t, lds);
         rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
     }
 }
