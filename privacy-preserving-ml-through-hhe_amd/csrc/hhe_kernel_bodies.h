@@ -236,8 +236,12 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 // invariant).  LAZY8 (all moduli of the launch < 2^60, i.e. 16q <= 2^64): fold once per round instead -- X >= 8q ? X - 8q
 // at the round's first stage, then up to four stages grow it to < 16q, which still fits 64 bits.  Saves RHO-1 of every RHO
 // conditional subtractions; the values stay congruent, so every fully reduced result is unchanged.
-template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS, bool FW16 = false>
-HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
+// TWL (row kernel, 256-point rows): the twiddles of stages 0..TWL_STAGES-1 of the tile's rows sit in LDS (ks_row_twiddle_fill)
+// and the rounds inside those stages read them there instead of from the global tables.
+constexpr int TWL_STAGES = 6;                                 // the first two radix-8 rounds of NttSched<8, 512>
+constexpr int TWL_ROW = (1 << TWL_STAGES) + 1;                // pairs per row: heap index 2^s + block, one pad pair (rows on distinct 16-byte slots)
+template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS, bool FW16 = false, bool TWL = false>
+HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, const u64 *twl = nullptr)
 {
     const NttGeom g = ntt_geom<(CC >= 0 ? LOGM : -1), CC>(a, bx, by);
     const ModDev m = mod_at_u(a.mods, g.mod_index);
@@ -254,6 +258,8 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
         const int x0 = (hi << (LOGM - S0)) + lo;
         const int P = STRIDED ? 1 : g.N_over_M + g.tile * g.C + lane;
         const int tb = (P << S0) + hi;
+        constexpr bool IN_LDS = TWL && !STRIDED && S0 + RHO <= TWL_STAGES;
+        const u64 *tl = twl + 2 * (size_t)(lane * TWL_ROW);   // this row's heap
         u64 v[RAD];
 #pragma unroll
         for (int k = 0; k < RAD; k++) v[k] = lds[(x0 + (k << LO_BITS)) * g.pitch + lane];
@@ -264,7 +270,8 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 #pragma unroll
                 for (int b = 0; b < (1 << u); b++) {
                     u64 w, ws;
-                    if (FW16) { const U2 tw = ld2g(W + 2 * (size_t)((tb << u) + b)); w = tw.a; ws = tw.b; }
+                    if (IN_LDS) { const U2 tw = ld2(tl + 2 * ((1 << (S0 + u)) + (hi << u) + b)); w = tw.a; ws = tw.b; }
+                    else if (FW16) { const U2 tw = ld2g(W + 2 * (size_t)((tb << u) + b)); w = tw.a; ws = tw.b; }
                     else { w = W[(tb << u) + b]; ws = WS[(tb << u) + b]; }
 #pragma unroll
                     for (int j = 0; j < half; j++) {
@@ -292,7 +299,7 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds)
                 const int half = 1 << (RHO - 1 - u);
 #pragma unroll
                 for (int b = 0; b < (1 << u); b++) {
-                    const U2 tw = ld2g(W + 2 * (size_t)((tb << u) + b));
+                    const U2 tw = IN_LDS ? ld2(tl + 2 * ((1 << (S0 + u)) + (hi << u) + b)) : ld2g(W + 2 * (size_t)((tb << u) + b));
                     const u64 w = tw.a, ws = tw.b;
 #pragma unroll
                     for (int j = 0; j < half; j++) {
@@ -740,6 +747,25 @@ constexpr int KSROW_THREADS = (1 << KSROW_TILE_LOG) / 8;             // 8 points
 constexpr int KSROW_SCHED = 512;                                     // NttSched selector of the 8-points-per-lane (radix-8/4) schedules
 constexpr int KSROW_NP = (1 << KSROW_TILE_LOG) / 2 / KSROW_THREADS;  // pairs per lane of a tile
 constexpr int KSROW_LDS = (1 << KSROW_TILE_LOG) + 512;
+// (w, ws) of stages 0..TWL_STAGES-1 for the C rows of this tile -> LDS, heap order per row.  The table index of stage s,
+// block k of row P is (P << s) + k (the same index ntt_body_round forms), P = N/M + global row.
+constexpr int KSROW_TWL = (1 << (KSROW_TILE_LOG - 8)) * TWL_ROW * 2;  // words, for 256-point rows
+template <int CM, int CC>
+HD void ks_row_twiddle_fill(const NttArgs &a, int bx, int J, bool inverse, int tid, u64 *twl)
+{
+    const NttGeom g = ntt_geom<CM, CC>(a, bx, J);
+    const ModDev m = mod_at_u(a.mods, g.mod_index);
+    const gptr tab = as_global(inverse ? m.iw : m.fw);
+    for (int e = tid; e < (g.C << TWL_STAGES); e += KSROW_THREADS) {
+        const int row = e >> TWL_STAGES, h = e & ((1 << TWL_STAGES) - 1);
+        if (h == 0) continue;
+        int s = 0;
+        while ((2 << s) <= h) s++;
+        const int P = g.N_over_M + g.tile * g.C + row;
+        const U2 tw = ld2g(tab + 2 * (size_t)((P << s) + (h - (1 << s))));
+        st2(twl + 2 * (size_t)(row * TWL_ROW + h), tw);
+    }
+}
 // after the forward rounds of digit I: acc_k[pair] += T * key[I][k][J]   (Shoup product in [0,2q); sums folded below 2q
 // after every fourth digit, so they never exceed 8q < 2^64)
 template <int CM, int CC>

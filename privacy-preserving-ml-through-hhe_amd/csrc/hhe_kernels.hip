@@ -72,41 +72,41 @@ int rt_stream_wait_event(rt_stream s, void *ev) { return rt_check(hipStreamWaitE
 
 // CC = tile columns as a compile-time constant (full tiles) or -1 (ragged tiles of small N: taken from the arguments);
 // T = lanes per workgroup (256: radix-16 rounds, 512: radix-8 rounds)
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH = T>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH = T, bool TWL = false>
 struct NttRounds {
     static constexpr int R = NttSched<LOGM, SCH>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
     template <int I, int S0, bool LAZY8 = false>
-    static __device__ __forceinline__ void fwd(const NttArgs &a, int bx, int by, u64 *lds)
+    static __device__ __forceinline__ void fwd(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl)
     {
         if constexpr (I < R) {
             constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512>(a, bx, by, threadIdx.x, lds);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL>(a, bx, by, threadIdx.x, lds, twl);
             __syncthreads();
-            fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
+            fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds, twl);
         }
     }
     template <int I, int SEND, bool LAZY8 = false>
-    static __device__ __forceinline__ void inv(const NttArgs &a, int bx, int by, u64 *lds)
+    static __device__ __forceinline__ void inv(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl)
     {
         if constexpr (I >= 0) {
             constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC, T>(a, bx, by, threadIdx.x, lds);
+            ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC, T, false, TWL>(a, bx, by, threadIdx.x, lds, twl);
             __syncthreads();
-            inv<I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
+            inv<I - 1, SEND - RHO, LAZY8>(a, bx, by, lds, twl);
         }
     }
 };
 // the register rounds of one pass over the tile staged in LDS (each round ends with a barrier)
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int SCH = T>
-static __device__ __forceinline__ void ntt_tile_rounds(const NttArgs &a, int bx, int by, u64 *lds)
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int SCH = T, bool TWL = false>
+static __device__ __forceinline__ void ntt_tile_rounds(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl = nullptr)
 {
     if constexpr (!INVERSE) {
-        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH>::template fwd<0, 0, true>(a, bx, by, lds);
-        else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH>::template fwd<0, 0, false>(a, bx, by, lds);
+        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, true>(a, bx, by, lds, twl);
+        else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, false>(a, bx, by, lds, twl);
     } else {
-        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, true>(a, bx, by, lds);
-        else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, false>(a, bx, by, lds);
+        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, true>(a, bx, by, lds, twl);
+        else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, false>(a, bx, by, lds, twl);
     }
 }
 
@@ -253,7 +253,11 @@ void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s)
 template <int LOGM>
 __global__ void __launch_bounds__(KSROW_THREADS, KSROW_THREADS / 64) ks_row_kernel(NttArgs a, KsRowArgs x, NttArgs c0)
 {
-    __shared__ u64 lds[KSROW_LDS];
+    // 256-point rows: the twiddles of the first two rounds of the tile's rows are staged in LDS once per direction (one
+    // array: tile | twiddle heap) and serve the L digit transforms / the inverse transforms of the workgroup
+    constexpr bool TWL = LOGM == 8;
+    __shared__ u64 lds[KSROW_LDS + (TWL ? KSROW_TWL : 0)];
+    u64 *const twl = TWL ? lds + KSROW_LDS : nullptr;
     constexpr int CC = KSROW_TILE_LOG - LOGM, T = KSROW_THREADS, SCH = KSROW_SCHED;
     // the first c0.count polynomials of the grid are an ordinary forward row pass (the c0 branch of the previous rotation
     // step with its mod-down epilogue): memory-bound tiles that run beside the arithmetic-bound key-switch tiles
@@ -269,11 +273,13 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_THREADS / 64) ks_row_kern
     u64 acc0[2 * KSROW_NP], acc1[2 * KSROW_NP];
 #pragma unroll
     for (int k = 0; k < 2 * KSROW_NP; k++) { acc0[k] = 0; acc1[k] = 0; }
+    if (TWL) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, false, tid, twl);
     for (int I = 0; I < x.L; I++) {
         const int by = (b * x.L + I) * x.K + J;
         ntt_body_load<false, false, LOGM, CC, T>(a, bx, by, tid, lds);
         __syncthreads();
-        ntt_tile_rounds<LOGM, false, false, CC, T, SCH>(a, bx, by, lds);
+        ntt_tile_rounds<LOGM, false, false, CC, T, SCH, TWL>(a, bx, by, lds, twl);
+        if (TWL && I == x.L - 1) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, tid, twl);  // behind the key products; every wave is past the forward rounds
         ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, tid, lds, acc0, acc1);
         __syncthreads();
     }
@@ -281,23 +287,23 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_THREADS / 64) ks_row_kern
         if (x.U0) {  // generic key switch: S_0[j] is inverse-transformed as well
             ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
             __syncthreads();
-            ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
+            ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds, twl);
             ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U0 + (size_t)b * x.u_stride + (size_t)J * n);
             __syncthreads();
         } else ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
         ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
         __syncthreads();
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds, twl);
         ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U1 + (size_t)b * x.u_stride + (size_t)J * n);
     } else {
         ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
         __syncthreads();
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds, twl);
         ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 0) * n);
         __syncthreads();
         ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
         __syncthreads();
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH>(a, bx, J, lds);
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds, twl);
         ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 1) * n);
     }
 }

@@ -31,34 +31,34 @@ int rt_event_record(void *, rt_stream) { return 0; }
 int rt_event_sync(void *) { return 0; }
 int rt_stream_wait_event(rt_stream, void *) { return 0; }
 
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int S0, bool LAZY8 = false>
-static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds)
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int S0, bool LAZY8 = false, bool TWL = false>
+static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl)
 {
     if constexpr (I < NttSched<LOGM, SCH>::R) {
         constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512>(a, bx, by, t, lds);
-        rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, I + 1, S0 + RHO, LAZY8>(a, bx, by, lds);
+        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL>(a, bx, by, t, lds, twl);
+        rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, I + 1, S0 + RHO, LAZY8, TWL>(a, bx, by, lds, twl);
     }
 }
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int SEND, bool LAZY8 = false>
-static void rounds_inv(const NttArgs &a, int bx, int by, u64 *lds)
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int SEND, bool LAZY8 = false, bool TWL = false>
+static void rounds_inv(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl)
 {
     if constexpr (I >= 0) {
         constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-        for (int t = 0; t < T; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC, T>(a, bx, by, t, lds);
-        rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, I - 1, SEND - RHO, LAZY8>(a, bx, by, lds);
+        for (int t = 0; t < T; t++) ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC, T, false, TWL>(a, bx, by, t, lds, twl);
+        rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, I - 1, SEND - RHO, LAZY8, TWL>(a, bx, by, lds, twl);
     }
 }
 // the register rounds of one pass over a staged tile (a barrier after each round = the end of the thread loop)
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int SCH = T>
-static void tile_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds)
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int SCH = T, bool TWL = false>
+static void tile_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl = nullptr)
 {
     if constexpr (!INVERSE) {
-        if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true>(a, bx, by, lds);
-        else rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, false>(a, bx, by, lds);
+        if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true, TWL>(a, bx, by, lds, twl);
+        else rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, false, TWL>(a, bx, by, lds, twl);
     }
-    else if (a.lazy8) rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, NttSched<LOGM, SCH>::R - 1, LOGM, true>(a, bx, by, lds);
-    else rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, NttSched<LOGM, SCH>::R - 1, LOGM, false>(a, bx, by, lds);
+    else if (a.lazy8) rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, NttSched<LOGM, SCH>::R - 1, LOGM, true, TWL>(a, bx, by, lds, twl);
+    else rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, NttSched<LOGM, SCH>::R - 1, LOGM, false, TWL>(a, bx, by, lds, twl);
 }
 template <int LOGM, bool STRIDED, bool INVERSE, bool FULL>
 static void pass_emu(const NttArgs &a, int gx, int gy)
@@ -116,7 +116,9 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
     const size_t n = (size_t)1 << a.logn;
 #pragma omp parallel
     {
-        std::vector<u64> lds(KSROW_LDS);
+        constexpr bool TWL = LOGM == 8;
+        std::vector<u64> lds(KSROW_LDS + (TWL ? KSROW_TWL : 0));
+        u64 *const twl = TWL ? lds.data() + KSROW_LDS : nullptr;
         std::vector<u64> acc0((size_t)T * 2 * KSROW_NP), acc1((size_t)T * 2 * KSROW_NP);
         auto A0 = [&](int t) { return &acc0[(size_t)t * 2 * KSROW_NP]; };
         auto A1 = [&](int t) { return &acc1[(size_t)t * 2 * KSROW_NP]; };
@@ -133,15 +135,17 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
                 const int b = y / x.K, J = y % x.K;
                 std::fill(acc0.begin(), acc0.end(), 0);
                 std::fill(acc1.begin(), acc1.end(), 0);
+                if (TWL) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, false, t, twl);
                 for (int I = 0; I < x.L; I++) {
                     const int by = (b * x.L + I) * x.K + J;
                     for (int t = 0; t < T; t++) ntt_body_load<false, false, LOGM, CC, T>(a, bx, by, t, lds.data());
-                    tile_rounds_emu<LOGM, false, false, CC, T, SCH>(a, bx, by, lds.data());
+                    tile_rounds_emu<LOGM, false, false, CC, T, SCH, TWL>(a, bx, by, lds.data(), twl);
+                    if (TWL && I == x.L - 1) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, t, twl);
                     for (int t = 0; t < T; t++) ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, t, lds.data(), A0(t), A1(t));
                 }
                 auto inverse_to = [&](std::vector<u64> &acc, u64 *out) {
                     for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), &acc[(size_t)t * 2 * KSROW_NP], nullptr);
-                    tile_rounds_emu<LOGM, false, true, CC, T, SCH>(a, bx, J, lds.data());
+                    tile_rounds_emu<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds.data(), twl);
                     for (int t = 0; t < T; t++) ks_row_store_phase<LOGM, CC>(a, bx, J, t, lds.data(), out);
                 };
                 if (J < x.L) {
