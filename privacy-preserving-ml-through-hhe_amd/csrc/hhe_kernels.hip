@@ -111,13 +111,14 @@ static __device__ __forceinline__ void ntt_tile_rounds(const NttArgs &a, int bx,
 }
 
 // one pass of one tile: load phase, register rounds through LDS, store phase
-template <int LOGM, bool STRIDED, bool INVERSE, bool FULL, int T = NTT_THREADS, int SCH = T, int TL = NttTile::LOG>
-static __device__ __forceinline__ void ntt_pass_tile(const NttArgs &a, int bx, int by, u64 *lds)
+template <int LOGM, bool STRIDED, bool INVERSE, bool FULL, int T = NTT_THREADS, int SCH = T, int TL = NttTile::LOG, bool TWL = false>
+static __device__ __forceinline__ void ntt_pass_tile(const NttArgs &a, int bx, int by, u64 *lds, u64 *twl = nullptr)
 {
     constexpr int CM = FULL ? LOGM : -1, CC = FULL ? TL - LOGM : -1;
+    if constexpr (TWL) ks_row_twiddle_fill<CM, CC>(a, bx, by, INVERSE, threadIdx.x, twl);
     ntt_body_load<STRIDED, INVERSE, CM, CC, T>(a, bx, by, threadIdx.x, lds);
     __syncthreads();
-    ntt_tile_rounds<LOGM, STRIDED, INVERSE, CC, T, SCH>(a, bx, by, lds);
+    ntt_tile_rounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>(a, bx, by, lds, twl);
     ntt_body_store<STRIDED, INVERSE, CM, CC, T>(a, bx, by, threadIdx.x, lds);
 }
 
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_THREADS / 64) ks_row_kern
     // step with its mod-down epilogue): memory-bound tiles that run beside the arithmetic-bound key-switch tiles
     const unsigned nc0 = (unsigned)c0.count << a.tiles_log;
     if (blockIdx.x < nc0) {
-        ntt_pass_tile<LOGM, false, false, true, T, SCH, KSROW_TILE_LOG>(c0, (int)(blockIdx.x & ((1u << a.tiles_log) - 1)), (int)(blockIdx.x >> a.tiles_log), lds);
+        ntt_pass_tile<LOGM, false, false, true, T, SCH, KSROW_TILE_LOG, TWL>(c0, (int)(blockIdx.x & ((1u << a.tiles_log) - 1)), (int)(blockIdx.x >> a.tiles_log), lds, twl);
         return;
     }
     const unsigned bid = blockIdx.x - nc0;

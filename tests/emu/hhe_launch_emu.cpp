@@ -125,8 +125,9 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
 #pragma omp for collapse(2)
         for (int by = 0; by < c0.count; by++)  // the c0-branch tiles of the grid: a plain forward row pass at this kernel's geometry
             for (int bx = 0; bx < gx; bx++) {
+                if (TWL) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(c0, bx, by, false, t, twl);
                 for (int t = 0; t < T; t++) ntt_body_load<false, false, LOGM, CC, T>(c0, bx, by, t, lds.data());
-                tile_rounds_emu<LOGM, false, false, CC, T, SCH>(c0, bx, by, lds.data());
+                tile_rounds_emu<LOGM, false, false, CC, T, SCH, TWL>(c0, bx, by, lds.data(), twl);
                 for (int t = 0; t < T; t++) ntt_body_store<false, false, LOGM, CC, T>(c0, bx, by, t, lds.data());
             }
 #pragma omp for collapse(2)
