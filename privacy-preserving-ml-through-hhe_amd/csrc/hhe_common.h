@@ -57,6 +57,8 @@ HD ModDev mod_at_u(const ModDev *mods, int i)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     i = __builtin_amdgcn_readfirstlane(i);
+    const u64 p = (u64)mods;  // the table pointer too: the compiler sometimes keeps this kernel argument in VGPRs
+    mods = (const ModDev *)(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)p));
 #endif
     return mod_at(mods, i);
 }
