@@ -329,6 +329,30 @@ def test_fused_row_kernel_full_tiles(orc, api, emu_lib, mem, logn, bits):
     assert (mem.to_host(out)[0] == ref).all()
 
 
+def test_row_kernel_lds_twiddle_heap_n32768(orc, api, emu_lib, mem):
+    """N = 2^15 (256-point rows): ks_row_kernel stages the twiddles of its first two rounds in LDS, for the digit
+    transforms, the inverse transforms and the c0 tiles of its grid.  One whole transciphering (matmul loop: c0 tiles in the
+    grid) and the generic key switches (rotation, relinearize: S_0 inverse-transformed too), same words as the oracle."""
+    S = Setup(orc, 15, [50, 50, 50])
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    S.load_keys(X)
+    O = S.O
+    rng = np.random.default_rng(15)
+    ct = O.encrypt(S.pk, O.encode(rng.integers(0, S.t, S.n)), 9)
+    d = mem.to_dev(ct[None])
+    out = mem.empty((1,) + O.ct_shape)
+    X.rotate_rows(d, -1, out, 1)
+    assert (mem.to_host(out)[0] == O.rotate_rows(ct, -1, S.gk)[0]).all()
+    o3 = mem.empty((1, 3) + O.ct_shape[1:])
+    X.multiply(d, d, o3, 1)
+    X.relinearize(o3, out, 1)
+    assert (mem.to_host(out)[0] == O.relinearize(O.multiply(ct, ct), S.rk)).all()
+    pt = [(5 * i + 1) % 256 for i in range(128)]
+    cw, ncw = S.sym_blocks(orc, pt)
+    X.transcipher(mem.to_dev(S.enc_key), cw, ncw, [0], out)
+    assert (mem.to_host(out)[0] == O.transcipher_block(S.enc_key, S.rk, S.gk, cw[0], 0)).all()
+
+
 def test_two_threads_on_one_context_are_serialised(orc, api, emu_lib, mem, small):
     """the reference's gRPC handlers call one cipher object concurrently (CSPRPC.cpp:201-203): every C-ABI entry point
     holds the context's lock, so two threads on ONE context get the same words as sequential calls"""
