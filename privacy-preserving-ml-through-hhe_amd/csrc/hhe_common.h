@@ -85,6 +85,9 @@ struct KsConsts {
     u64 qsp_inv_s[HHE_MAXL];
     u64 qsp_mod[HHE_MAXL];    // q_sp mod q_j (FC leaf sums: galois(c0) enters the sum that is later multiplied by q_sp^-1)
     u64 qsp_mod_s[HHE_MAXL];
+    // KS1 epilogue in one expression: (v N^-1 - r + half) q_sp^-1 = v (N^-1 q_sp^-1) - r q_sp^-1 + half q_sp^-1  (mod q_j)
+    u64 ninv_qinv[HHE_MAXL], ninv_qinv_s[HHE_MAXL];  // N^-1 q_sp^-1 mod q_j and its Shoup quotient
+    u64 hq2[HHE_MAXL];                               // 2 q_j + (half q_sp^-1 mod q_j): keeps the lazy difference non-negative
 };
 
 struct NttArgs {
@@ -242,6 +245,9 @@ struct KsFinishArgs {  // SURVEY A.4 mod-down; S already INTT'd (coefficient for
     u64 qsp_inv_s[HHE_MAXL];
     u64 qsp_mod[HHE_MAXL];    // q_sp mod q_j (FC leaf sums: galois(c0) enters the sum that is later multiplied by q_sp^-1)
     u64 qsp_mod_s[HHE_MAXL];
+    // KS1 epilogue in one expression: (v N^-1 - r + half) q_sp^-1 = v (N^-1 q_sp^-1) - r q_sp^-1 + half q_sp^-1  (mod q_j)
+    u64 ninv_qinv[HHE_MAXL], ninv_qinv_s[HHE_MAXL];  // N^-1 q_sp^-1 mod q_j and its Shoup quotient
+    u64 hq2[HHE_MAXL];                               // 2 q_j + (half q_sp^-1 mod q_j): keeps the lazy difference non-negative
 };
 
 struct AddPlainArgs {

@@ -313,6 +313,9 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     for (int j = 0; j < L; ++j) {
         c->ksc.half_mod[j] = kf.half_mod[j]; c->ksc.qsp_inv[j] = kf.qsp_inv[j]; c->ksc.qsp_inv_s[j] = kf.qsp_inv_s[j];
         c->ksc.qsp_mod[j] = qsp % dq[j]; c->ksc.qsp_mod_s[j] = shoup_quot(c->ksc.qsp_mod[j], dq[j]);
+        c->ksc.ninv_qinv[j] = nt_mulmod(mods[j].ninv, kf.qsp_inv[j], dq[j]);
+        c->ksc.ninv_qinv_s[j] = shoup_quot(c->ksc.ninv_qinv[j], dq[j]);
+        c->ksc.hq2[j] = 2 * dq[j] + nt_mulmod(kf.half_mod[j], kf.qsp_inv[j], dq[j]);
     }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);

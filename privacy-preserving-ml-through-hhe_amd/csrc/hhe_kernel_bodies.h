@@ -382,6 +382,7 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
     if (!LAST || (!INVERSE && a.store_op == STORE_LAZY)) { st2_stream(dst + gi, U2{v[0], v[1]}); return; }
     if (INVERSE) {
         const bool st = a.store_op == STORE_SCALE_T;
+        if (a.store_op != STORE_KS1 && a.store_op != STORE_KSF)  // the mod-down epilogues fold N^-1 into their own product
         for (int k = 0; k < 2; k++) {
             v[k] = csub(shoup_lazy_n(v[k], st ? m.ninv_t : m.ninv, st ? m.ninv_t_s : m.ninv_s, m.nq), m.nq);
         }
@@ -408,8 +409,9 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             const u64 rr[2] = {pre.s.a, pre.s.b}, bb[2] = {pre.d.a, pre.d.b};
             u64 o[2];
             for (int k = 0; k < 2; k++) {
-                u64 t = addmod(submod(v[k], reduce64(rr[k], m), q), a.ks.half_mod[j], q);
-                t = shoup_mul(t, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
+                const u64 pa = shoup_lazy_n(v[k], a.ks.ninv_qinv[j], a.ks.ninv_qinv_s[j], m.nq);   // as in KS1 below
+                const u64 pb = shoup_lazy_n(rr[k], a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], m.nq);
+                const u64 t = csub(csub(csub(pa + a.ks.hq2[j] - pb, m.nq << 2), m.nq << 1), m.nq);
                 o[k] = base ? addmod(t, bb[k], q) : t;
             }
             st2(a.aux_out + pbase + gi, U2{o[0], o[1]});
@@ -419,8 +421,10 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             const int j = g.poly % a.L;
             const u64 rr[2] = {pre.s.a, pre.s.b};
             for (int k = 0; k < 2; k++) {
-                u64 o = addmod(submod(v[k], reduce64(rr[k], m), q), a.ks.half_mod[j], q);
-                o = shoup_mul(o, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], q);
+                // (v N^-1 - r + half) q_sp^-1 mod q as two lazy products (any 64-bit input): no separate N^-1 scaling, no reduction of r
+                const u64 pa = shoup_lazy_n(v[k], a.ks.ninv_qinv[j], a.ks.ninv_qinv_s[j], m.nq);
+                const u64 pb = shoup_lazy_n(rr[k], a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], m.nq);
+                u64 o = csub(csub(csub(pa + a.ks.hq2[j] - pb, m.nq << 2), m.nq << 1), m.nq);
                 u32 idx = (u32)(gi + k);
                 if (a.gal_elt) {
                     const u64 raw = (u64)(gi + k) * a.gal_elt;
