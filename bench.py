@@ -391,7 +391,7 @@ def main():
                          "algorithmic_bytes_per_launch": per_launch,
                          "algorithmic_bytes_definition": "per ciphertext of a rotation step: (L*K + 5L) P read + (5L + 2) P written, P = 8N (DESIGN.md section 4)",
                          "kernel_time_over_path_time": total_ms / path_ms,
-                         "note": "the library runs two chunks of the batch on two internal streams, so launches of the two streams overlap: durations are those of overlapping launches (as rocprofv3 records them) and their sum exceeds the path time"})
+                         "note": "the chunks of a batch run one after the other on one internal stream (HHE_STREAMS=1, the default), so a launch's duration is its own; with HHE_STREAMS=2 launches of the two streams overlap and their durations stretch"})
             # PMC-derived figures of the same kernel come from a committed rocprofv3 run; they are only reported while the
             # kernel sources are the ones that run was made with
             if os.path.exists(PMC_PROFILE) and args.params == "config2":

@@ -105,7 +105,8 @@ struct hhe_ctx {
     // the transciphering path uses to process chunks of a batch concurrently (each with its own workspace)
     Lane lanes[1 + HHE_MAX_STREAMS];
     Lane *w = &lanes[0];
-    int nstreams = 2;      // internal streams used by hhe_pasta3_transcipher (0 = caller's stream only)
+    int nstreams = 1;      // internal streams used by hhe_pasta3_transcipher (0 = caller's stream only).  One: since the row kernel lost its
+                           // exposed round trips two overlapping chunks give the same throughput (289 vs 289 /s) and make every kernel's duration depend on its neighbour
     size_t chunk = 128;    // items per chunk (HHE_CHUNK); measured 211 /s at 32, 221 at 64, 225 at 128 items (round 1)
     void *ev_fork = nullptr;
 

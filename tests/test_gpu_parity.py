@@ -248,7 +248,7 @@ def test_babystep_giantstep_variant(orc, api, lib, mem):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"},
+    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "2"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"},
 ])
 def test_execution_knobs_are_result_neutral(orc, api, lib, mem, small, monkeypatch, knobs):
     pt = [(3 * i + 1) % 256 for i in range(300)]

@@ -224,7 +224,7 @@ def test_reference_n65536_29_prime_context_is_accepted(orc, api, emu_lib, mem):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"},
+    {"HHE_STREAMS": "0"}, {"HHE_STREAMS": "2"}, {"HHE_STREAMS": "3", "HHE_CHUNK": "1"}, {"HHE_MATMUL": "0", "HHE_STREAMS": "1"},
 ])
 def test_every_execution_knob_gives_the_same_words(orc, api, emu_lib, mem, small, monkeypatch, knobs):
     """chunking / streams / the literal op-by-op schedule only change scheduling"""
