@@ -1074,9 +1074,9 @@ extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, siz
     if (!c || !vi || !w || !out || W == 0 || B == 0 || n_inputs == 0 || n_inputs > c->n / 2 || relin_slot < 0 || relin_slot >= HHE_RELIN_SLOTS)
         return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
     if (!c->d_rk_slot[relin_slot]) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
-    // chunks keep the key-switch working set (digit transforms) inside the Infinity Cache; a chunk is a multiple of W
-    // so that item i of a chunk still uses weight row i % W.  Chunks are independent: they run round-robin on the
-    // internal streams (as in hhe_pasta3_transcipher), which fills the tails of each other's small launches.
+    // chunks bound the key-switch working set (digit transforms per trie level); a chunk is a multiple of W so that item i
+    // of a chunk still uses weight row i % W.  Chunks are independent: with more than one internal stream (HHE_STREAMS)
+    // they run round-robin on the streams, as in hhe_pasta3_transcipher.
     size_t per = c->fc_chunk ? c->fc_chunk : B;
     if (per < B) per = std::max<size_t>(W, per / W * W);
     per = std::min(per, B);
