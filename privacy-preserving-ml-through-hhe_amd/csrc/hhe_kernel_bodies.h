@@ -743,14 +743,17 @@ HD void ks_corr_body(const KsCorrArgs &a, size_t gid)
 // ------------------------------------------------------------------ fused key-switch row kernel (KsRowArgs)
 // Phases of one workgroup (b, J, row tile); fa / ia are the argument blocks of the forward / inverse row pass whose
 // geometry and moduli the shared round bodies read (poly index `by` only selects the modulus there).
+// Tile = 512 points on ONE wave (64 lanes x 8 points): sixteen independent single-wave workgroups per CU, whose barriers cost
+// nothing and whose phases interleave freely.  Measured (transcipherings/s, one box, three alternating runs each): 2048 points
+// on 256 lanes 292.8, 1024 points on 128 lanes 294.6, 512 points on 64 lanes 297.5.
 #ifndef KSROW_TL
-#define KSROW_TL 11
+#define KSROW_TL 9
 #endif
 constexpr int KSROW_TILE_LOG = KSROW_TL;                             // points per tile of this kernel (log2)
 constexpr int KSROW_THREADS = (1 << KSROW_TILE_LOG) / 8;             // 8 points per lane: 2 x 8 lazy sums + a radix-8 round fit the 128-VGPR budget of 4 waves per SIMD
 constexpr int KSROW_SCHED = 512;                                     // NttSched selector of the 8-points-per-lane (radix-8/4) schedules
 constexpr int KSROW_NP = (1 << KSROW_TILE_LOG) / 2 / KSROW_THREADS;  // pairs per lane of a tile
-constexpr int KSROW_LDS = (1 << KSROW_TILE_LOG) + 512;
+constexpr int KSROW_LDS = (1 << KSROW_TILE_LOG) + 256;  // words: M rows of pitch C + 1 = 2^TL + M, M <= 256
 // (w, ws) of stages 0..TWL_STAGES-1 for the C rows of this tile -> LDS, heap order per row.  The table index of stage s,
 // block k of row P is (P << s) + k (the same index ntt_body_round forms), P = N/M + global row.
 constexpr int KSROW_TWL = (1 << (KSROW_TILE_LOG - 8)) * TWL_ROW * 2;  // words, for 256-point rows

@@ -251,8 +251,9 @@ void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s)
 // 8 points per lane: the 2 x 8 lazy sums of a lane live in registers beside a radix-8 round inside the 128-VGPR budget of
 // 4 waves per SIMD.  Measured alternatives (round 2, config 2, transcipherings/s): 4096-point tiles on 256 lanes x 16 points
 // need 173+ VGPRs -- 200 at 3 waves per SIMD (spills), 237 at 2 waves per SIMD; 4096-point tiles on 512 lanes: 238.
+// The tile size (csrc/hhe_kernel_bodies.h, KSROW_TL) is now one wave's worth; the launch bound asks for 4 waves per SIMD.
 template <int LOGM>
-__global__ void __launch_bounds__(KSROW_THREADS, KSROW_THREADS / 64) ks_row_kernel(NttArgs a, KsRowArgs x, NttArgs c0)
+__global__ void __launch_bounds__(KSROW_THREADS, 4) ks_row_kernel(NttArgs a, KsRowArgs x, NttArgs c0)
 {
     // 256-point rows: the twiddles of the first two rounds of the tile's rows are staged in LDS once per direction (one
     // array: tile | twiddle heap) and serve the L digit transforms / the inverse transforms of the workgroup
