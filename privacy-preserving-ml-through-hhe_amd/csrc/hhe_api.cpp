@@ -495,6 +495,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
         NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
         a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
         a.store_op = STORE_LAZY;
+        if (c->strided_nofold && a.lazy8) a.lazy8 = 2;
         return a;
     };
     // N >= 4096 -- four launches per step: strided pass of the digit transforms (+ the held-back c0 branch's strided pass in
@@ -550,6 +551,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.acc = accp0;
             a.aux_r = c->w->ws_S + (rowk ? (size_t)(i & 1) * K * n : 0);
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g; a.mul_s_off = pdiag_words;
+            if (c->strided_nofold && a.lazy8) a.lazy8 = 2;  // LOAD_RNEG inputs are canonical
             k5 = a; k5_pending = true;  // launched in the grid of the next step's digit transforms
         }
         cur ^= 1;

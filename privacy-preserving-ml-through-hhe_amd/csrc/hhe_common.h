@@ -108,7 +108,8 @@ struct NttArgs {
     u32 load_einv;     // first pass: > 0 => the source is read through a Galois map (apply_galois as a gather): elt^-1 mod 2N;
                        // negation is modulo the SOURCE limb's prime (the digit source d_I lives mod q_I whatever the transform's modulus)
     u32 *zero_flag;    // LOAD_DIGIT: set to 1 when a coefficient equals 0 (the shared-digit FC path then falls back)
-    int lazy8;         // every modulus of the launch is below 2^60: forward butterflies correct X once per register round ([0,16q) range)
+    int lazy8;         // every modulus of the launch is below 2^60: forward butterflies correct X once per register round ([0,16q) range);
+                       // 2: additionally a forward STRIDED pass folds nothing (inputs < 2q, <= 7 stages of +2q each stay below 16q)
     int digit_reduce;  // DIGIT: 1 if some q_I >= 4*q_J (else the lazy butterflies absorb the unreduced residue)
     u64 t;          // LIFT: plain modulus
     // STORE_MUL / STORE_MAC multiplier (NTT form): (mul_ptrs ? mul_ptrs[p / mul_item_polys] : mul)

@@ -334,6 +334,9 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
         for (int i = 0; i < L; ++i) qmax = std::max(qmax, c->q[i]);
         for (int i = 0; i < K; ++i) qmin = std::min(qmin, c->q[i]);
         c->digit_reduce = (qmax / 4 >= qmin) ? 1 : 0;
+        int n1, n2;
+        ntt_split(logn, n1, n2);
+        c->strided_nofold = (qmax / 2 < qmin && n1 <= 7 && ntt_lazy8(c, 0, K)) ? 1 : 0;
     }
     kf.mods = c->d_mods; kf.logn = logn; kf.L = L; kf.K = K;
     ap.mods = c->d_mods; ap.logn = logn; ap.L = L;

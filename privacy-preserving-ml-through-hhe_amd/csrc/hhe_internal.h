@@ -66,6 +66,8 @@ struct hhe_ctx {
     int nmod = 0;                  // K + (L+1) + 1
     int mod_t = 0;                 // index of the plain modulus
     int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
+    int strided_nofold = 0;        // 1 when the matmul loop's forward strided pass needs no range fold at all (NttArgs::lazy8 = 2): inputs
+                                   // below 2q (every data prime below 2x every key prime), at most 7 stages, 16q <= 2^64
     u64 fc_fallbacks = 0;          // how often the shared-digit path had to be recomputed exactly
     int fc_shared = 1;             // FC rotation trie: children of a node share the digit transforms of its c1 (HHE_FC_SHARED; 2 = force the fallback, tests)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)

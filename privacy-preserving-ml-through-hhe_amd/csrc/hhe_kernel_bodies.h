@@ -240,7 +240,7 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 // and the rounds inside those stages read them there instead of from the global tables.
 constexpr int TWL_STAGES = 6;                                 // the first two radix-8 rounds of NttSched<8, 512>
 constexpr int TWL_ROW = (1 << TWL_STAGES) + 1;                // pairs per row: heap index 2^s + block, one pad pair (rows on distinct 16-byte slots)
-template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS, bool FW16 = false, bool TWL = false>
+template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS, bool FW16 = false, bool TWL = false, bool NOFOLD = false>
 HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, const u64 *twl = nullptr)
 {
     const NttGeom g = ntt_geom<(CC >= 0 ? LOGM : -1), CC>(a, bx, by);
@@ -277,7 +277,7 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
                     for (int j = 0; j < half; j++) {
                         const int k0 = b * 2 * half + j, k1 = k0 + half;
                         u64 x = v[k0];
-                        if (LAZY8) { if (u == 0) x = csub(x, nq8); }
+                        if (LAZY8) { if (u == 0 && !NOFOLD) x = csub(x, nq8); }
                         else x = csub(x, nq2);
                         const u64 y = shoup_lazy_n(v[k1], w, ws, nq);
                         v[k0] = x + y;

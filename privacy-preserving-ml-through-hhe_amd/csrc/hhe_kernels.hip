@@ -76,14 +76,14 @@ template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH = T, bool
 struct NttRounds {
     static constexpr int R = NttSched<LOGM, SCH>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
-    template <int I, int S0, bool LAZY8 = false>
+    template <int I, int S0, bool LAZY8 = false, bool NOFOLD = false>
     static __device__ __forceinline__ void fwd(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl)
     {
         if constexpr (I < R) {
             constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL>(a, bx, by, threadIdx.x, lds, twl);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL, NOFOLD>(a, bx, by, threadIdx.x, lds, twl);
             __syncthreads();
-            fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds, twl);
+            fwd<I + 1, S0 + RHO, LAZY8, NOFOLD>(a, bx, by, lds, twl);
         }
     }
     template <int I, int SEND, bool LAZY8 = false>
@@ -102,7 +102,8 @@ template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int
 static __device__ __forceinline__ void ntt_tile_rounds(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl = nullptr)
 {
     if constexpr (!INVERSE) {
-        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, true>(a, bx, by, lds, twl);
+        if (STRIDED && LOGM <= 7 && a.lazy8 == 2) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, true, true>(a, bx, by, lds, twl);
+        else if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, true>(a, bx, by, lds, twl);
         else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, false>(a, bx, by, lds, twl);
     } else {
         if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, true>(a, bx, by, lds, twl);

@@ -31,13 +31,13 @@ int rt_event_record(void *, rt_stream) { return 0; }
 int rt_event_sync(void *) { return 0; }
 int rt_stream_wait_event(rt_stream, void *) { return 0; }
 
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int S0, bool LAZY8 = false, bool TWL = false>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int S0, bool LAZY8 = false, bool TWL = false, bool NOFOLD = false>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl)
 {
     if constexpr (I < NttSched<LOGM, SCH>::R) {
         constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL>(a, bx, by, t, lds, twl);
-        rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, I + 1, S0 + RHO, LAZY8, TWL>(a, bx, by, lds, twl);
+        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL, NOFOLD>(a, bx, by, t, lds, twl);
+        rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, I + 1, S0 + RHO, LAZY8, TWL, NOFOLD>(a, bx, by, lds, twl);
     }
 }
 template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int SEND, bool LAZY8 = false, bool TWL = false>
@@ -54,7 +54,8 @@ template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int
 static void tile_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl = nullptr)
 {
     if constexpr (!INVERSE) {
-        if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true, TWL>(a, bx, by, lds, twl);
+        if (STRIDED && LOGM <= 7 && a.lazy8 == 2) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true, TWL, true>(a, bx, by, lds, twl);
+        else if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true, TWL>(a, bx, by, lds, twl);
         else rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, false, TWL>(a, bx, by, lds, twl);
     }
     else if (a.lazy8) rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, NttSched<LOGM, SCH>::R - 1, LOGM, true, TWL>(a, bx, by, lds, twl);
