@@ -25,6 +25,12 @@ extern "C" {
 #endif
 
 typedef struct hhe_ctx hhe_ctx;
+/* One seal::RelinKeys / seal::GaloisKeys OBJECT on the device (keys with identity).  The reference's CSP holds several, made by
+ * the same key generator with different randomness, and names one at every call: PASTA_SEAL(context, pk, sk, analyst rk, analyst gk)
+ * (src/examples/CSP/CSP.cpp:238-242), flatten(record, tmp, csp_he_gk) (:271-278), relinearize_inplace(record, csp rk) (:306),
+ * encrypted_vec_sum(.., analyst_he_gk, ..) (:312-316); the objects are created at src/examples/Analyst/Analyst.cpp:62-94.
+ * Which keys a rotation finds decides its NAF decomposition (seal/evaluator.h:955-1060) and the ciphertext words. */
+typedef struct hhe_keyset hhe_keyset;
 
 enum {
     HHE_OK = 0,
@@ -68,13 +74,25 @@ int hhe_ctx_profile_read(hhe_ctx *c, char *kernel_name, size_t name_cap, uint64_
  * {"root" i<K, "bsk" i<=L (B_0.., m_sk), "gamma", "galois_elt" i=step, "fc_fallbacks"} */
 uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i);
 
-/* ---- keys: the by-value seal::RelinKeys / seal::GaloisKeys members of SEALZpCipher
- *      (src/pasta/SEAL_Cipher.h:28-31; ctor SEAL_Cipher.cpp:9-36).  Uploaded once, cached in HBM. ---- */
+/* ---- keys.  Key words must be reduced modulo their coefficient primes (what SEAL's safe load checks, is_data_valid_for):
+ *      the kernels multiply them through Shoup quotients; an upload with a word >= its prime fails with HHE_ERR_INVALID.
+ *      The DEFAULT set of a context = the by-value seal::RelinKeys / seal::GaloisKeys members of SEALZpCipher
+ *      (src/pasta/SEAL_Cipher.h:28-31; ctor SEAL_Cipher.cpp:9-36): every entry point without a key-set argument uses it. ---- */
 int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk_hptr); /* slot 0: the key PASTA_SEAL was constructed with */
 /* further RelinKeys objects (e.g. the CSP's own csp_rk used at CSP.cpp:306); slot < 4 */
 int hhe_set_relin_key_slot(hhe_ctx *c, int slot, const uint64_t *ksk_hptr);
 int hhe_set_galois_key(hhe_ctx *c, uint32_t galois_elt, const uint64_t *ksk_hptr);
 int hhe_has_galois_key(const hhe_ctx *c, uint32_t galois_elt);
+/* Key sets: one per RelinKeys / GaloisKeys object of the caller (a set may hold both kinds).  Uploaded once, resident in HBM
+ * with everything derived from its keys (Shoup quotient tables, FC correction tables) until destroyed; using a set never
+ * touches another set.  A set belongs to the context it was created on and must be destroyed before that context
+ * (hhe_ctx_destroy releases forgotten ones).  In the *_ks entry points below a NULL set means the context's default set. */
+int hhe_keyset_create(hhe_ctx *c, hhe_keyset **out);
+void hhe_keyset_destroy(hhe_keyset *ks);
+int hhe_keyset_set_relin(hhe_keyset *ks, const uint64_t *ksk_hptr);                        /* RelinKeys::key(2) */
+int hhe_keyset_set_galois(hhe_keyset *ks, uint32_t galois_elt, const uint64_t *ksk_hptr);  /* GaloisKeys::key(galois_elt) */
+int hhe_keyset_has_galois(const hhe_keyset *ks, uint32_t galois_elt);                      /* GaloisKeys::has_key */
+int hhe_keyset_has_relin(const hhe_keyset *ks);
 
 /* ---- device memory helpers for callers without their own HIP allocator ---- */
 void *hhe_malloc(size_t bytes);
@@ -102,6 +120,11 @@ int hhe_apply_galois(hhe_ctx *c, const uint64_t *ct_dptr, uint32_t galois_elt, u
 /* Evaluator::rotate_rows / rotate_columns incl. NAF fallback (seal/evaluator.h:955-1060) */
 int hhe_rotate_rows(hhe_ctx *c, const uint64_t *ct_dptr, int step, uint64_t *out_dptr, size_t B);
 int hhe_rotate_columns(hhe_ctx *c, const uint64_t *ct_dptr, uint64_t *out_dptr, size_t B);
+/* the same with the GaloisKeys object the call names, as Evaluator::rotate_rows(ct, step, galois_keys, out) does: a step whose
+ * element is not in THIS set is NAF-decomposed over the keys of this set, whatever other sets hold */
+int hhe_apply_galois_ks(hhe_ctx *c, const hhe_keyset *gk, const uint64_t *ct_dptr, uint32_t galois_elt, uint64_t *out_dptr, size_t B);
+int hhe_rotate_rows_ks(hhe_ctx *c, const hhe_keyset *gk, const uint64_t *ct_dptr, int step, uint64_t *out_dptr, size_t B);
+int hhe_rotate_columns_ks(hhe_ctx *c, const hhe_keyset *gk, const uint64_t *ct_dptr, uint64_t *out_dptr, size_t B);
 /* Evaluator::multiply (seal/evaluator.h:214-277; BEHZ) -> size-3 ct [B][3][L][N] */
 int hhe_multiply(hhe_ctx *c, const uint64_t *a_dptr, const uint64_t *b_dptr, uint64_t *out3_dptr, size_t B);
 /* Evaluator::relinearize_inplace (seal/evaluator.h:301-304) size 3 -> 2 */
@@ -109,6 +132,8 @@ int hhe_relinearize(hhe_ctx *c, const uint64_t *a3_dptr, uint64_t *out_dptr, siz
 /* the same with the RelinKeys object of `slot` (hhe_set_relin_key_slot): Evaluator::relinearize_inplace(record, csp_rk) at
  * src/examples/CSP/CSP.cpp:306 uses the CSP's keys, not the ones PASTA_SEAL was built with */
 int hhe_relinearize_slot(hhe_ctx *c, int slot, const uint64_t *a3_dptr, uint64_t *out_dptr, size_t B);
+/* ... or with the RelinKeys object as a key set */
+int hhe_relinearize_ks(hhe_ctx *c, const hhe_keyset *rk, const uint64_t *a3_dptr, uint64_t *out_dptr, size_t B);
 
 /* ---- the hot path ---- */
 /* PASTA_SEAL::decomposition / HE_decrypt (src/pasta/pasta_3_seal.cpp:106-172 / :42-104), batched over
@@ -121,6 +146,9 @@ int hhe_relinearize_slot(hhe_ctx *c, int slot, const uint64_t *a3_dptr, uint64_t
 int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key_dptr, const uint64_t *cw_hptr,
                            const uint32_t *ncw_hptr, const uint64_t *block_index_hptr, size_t B,
                            int use_bsgs, uint64_t *out_dptr);
+/* the same for a PASTA_SEAL constructed with the RelinKeys `rk` and the GaloisKeys `gk` (CSP.cpp:238-242: the analyst's) */
+int hhe_pasta3_transcipher_ks(hhe_ctx *c, const hhe_keyset *rk, const hhe_keyset *gk, const uint64_t *enc_key_dptr, const uint64_t *cw_hptr,
+                              const uint32_t *ncw_hptr, const uint64_t *block_index_hptr, size_t B, int use_bsgs, uint64_t *out_dptr);
 /* drop cached per-block public tables (matrices depend only on (nonce, block index)).  The cache is unbounded and grows by
  * (4 x 128 x L + 4) x N words per distinct block counter on first use -- 384 MiB at N = 2^15, L = 3; 1.07 GiB at the
  * reference defaults N = 2^14, L = 8; the babystep-giantstep variant adds the same again -- so a caller that walks through
@@ -131,12 +159,18 @@ int hhe_mask(hhe_ctx *c, const uint64_t *ct_dptr, const uint64_t *mask_vals_hptr
              uint64_t *out_dptr, size_t B);
 /* SEALZpCipher::flatten (src/pasta/SEAL_Cipher.cpp:170-181): blocks [S][nblocks][2][L][N] -> out [S][2][L][N] */
 int hhe_flatten(hhe_ctx *c, const uint64_t *blocks_dptr, size_t nblocks, uint64_t *out_dptr, size_t S);
+/* flatten(in, out, galois_keys) with the GaloisKeys object it is given (CSP.cpp:271-278 passes csp_he_gk, steps -128*i) */
+int hhe_flatten_ks(hhe_ctx *c, const hhe_keyset *gk, const uint64_t *blocks_dptr, size_t nblocks, uint64_t *out_dptr, size_t S);
 /* BaseCSP::decompose (src/examples/CSP/CSP.cpp:235-283): S records of nwords symmetric-ciphertext words (host, [S][nwords])
  * -> decomposition of every block + mask of the ragged last block (mask_last != 0: as hhe_pktnn_examples.cpp:620-626;
  * the CSP's own loop at CSP.cpp:264-269 masks a copy, i.e. has no effect: pass 0 to reproduce that) + flatten.
  * out [S][2][L][N] device.  Needs the PASTA keys plus Galois keys reaching steps -128*i (directly or through NAF). */
 int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key_dptr, const uint64_t *records_hptr, size_t S, size_t nwords,
                   int mask_last, uint64_t *out_dptr);
+/* the same with the three key objects BaseCSP::decompose names: `rk` / `gk` construct the PASTA_SEAL (CSP.cpp:238-242), `flatten_gk`
+ * is the GaloisKeys passed to flatten (CSP.cpp:271-278) */
+int hhe_decompose_ks(hhe_ctx *c, const hhe_keyset *rk, const hhe_keyset *gk, const hhe_keyset *flatten_gk, const uint64_t *enc_key_dptr,
+                     const uint64_t *records_hptr, size_t S, size_t nwords, int mask_last, uint64_t *out_dptr);
 /* FC row: sealhelper::packed_enc_multiply + Evaluator::relinearize_inplace + sealhelper::encrypted_vec_sum
  * (src/util/sealhelper.cpp:268-274, src/examples/CSP/CSP.cpp:306, sealhelper.cpp:379-392).
  * vi [B][2][L][N]; w: weight-row ciphertexts [W][2][L][N]; item i uses w[i % W]. out [B][2][L][N];
@@ -149,6 +183,10 @@ int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key_dptr, const uint64_t *reco
  * hhe_ctx_query("fc_fallbacks") counts those).  Synchronous: returns when the results are in out. */
 int hhe_fc_row(hhe_ctx *c, const uint64_t *vi_dptr, const uint64_t *w_dptr, size_t W, size_t n_inputs, int relin_slot,
                int default_galois_only, uint64_t *out_dptr, size_t B);
+/* the same with the key objects the CSP names: relinearize_inplace(prod, rk) (CSP.cpp:306) and encrypted_vec_sum(prod, sum, evaluator,
+ * gk, n) (CSP.cpp:312-316): a rotation step is one key switch exactly when `gk` holds its element, else its NAF terms over `gk` */
+int hhe_fc_row_ks(hhe_ctx *c, const hhe_keyset *rk, const hhe_keyset *gk, const uint64_t *vi_dptr, const uint64_t *w_dptr, size_t W,
+                  size_t n_inputs, uint64_t *out_dptr, size_t B);
 
 /* PASTA-3 public randomness for one block as the kernels consume it (host; src/pasta/pasta_3_plain.cpp:56-119,286-295):
  * mats [4][2][128][128], rcs [4][2][128] */
@@ -189,6 +227,11 @@ int hhe_seal_save_ciphertext(hhe_ctx *c, const uint64_t *ct_dptr, size_t ct_size
  * 2*index+1, seal/galoiskeys.h:48-74) */
 int hhe_seal_load_relin_keys(hhe_ctx *c, int slot, const uint8_t *bytes_hptr, size_t nbytes, size_t *consumed);
 int hhe_seal_load_galois_keys(hhe_ctx *c, const uint8_t *bytes_hptr, size_t nbytes, size_t *consumed, uint32_t *n_keys);
+/* the same into a key set (one set per loaded object).  All loads are all-or-nothing, as SEAL's load(context, ...) is: the whole
+ * object is decoded and validated on the host first; a malformed, truncated or over-long object leaves the target untouched.
+ * Inflated sizes are bounded by the largest legitimate object of the context (a few KB of zlib / zstd cannot expand into GBs). */
+int hhe_seal_load_relin_keys_ks(hhe_keyset *ks, const uint8_t *bytes_hptr, size_t nbytes, size_t *consumed);
+int hhe_seal_load_galois_keys_ks(hhe_keyset *ks, const uint8_t *bytes_hptr, size_t nbytes, size_t *consumed, uint32_t *n_keys);
 
 #ifdef __cplusplus
 }

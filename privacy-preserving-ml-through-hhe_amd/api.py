@@ -35,6 +35,9 @@ _SYMBOLS = [
     "hhe_pasta3_block_randomness", "hhe_pasta3_plain_keystream", "hhe_pasta3_plain_crypt", "hhe_decrypt",
     "hhe_ctx_profile", "hhe_ctx_profile_read", "hhe_relinearize_slot",
     "hhe_seal_load_ciphertext", "hhe_seal_save_ciphertext", "hhe_seal_load_relin_keys", "hhe_seal_load_galois_keys",
+    "hhe_keyset_create", "hhe_keyset_destroy", "hhe_keyset_set_relin", "hhe_keyset_set_galois", "hhe_keyset_has_galois", "hhe_keyset_has_relin",
+    "hhe_apply_galois_ks", "hhe_rotate_rows_ks", "hhe_rotate_columns_ks", "hhe_relinearize_ks", "hhe_pasta3_transcipher_ks",
+    "hhe_flatten_ks", "hhe_decompose_ks", "hhe_fc_row_ks", "hhe_seal_load_relin_keys_ks", "hhe_seal_load_galois_keys_ks",
 ]
 
 
@@ -66,6 +69,8 @@ def load_library(path=None):
     lib.hhe_free.argtypes = [C.c_void_p]
     lib.hhe_ctx_destroy.argtypes = [C.c_void_p]
     lib.hhe_pasta3_clear_block_cache.argtypes = [C.c_void_p]
+    lib.hhe_keyset_destroy.argtypes = [C.c_void_p]
+    lib.hhe_keyset_destroy.restype = None
     return lib
 
 
@@ -80,6 +85,62 @@ def _ptr(x):
         return C.c_void_p(x.ctypes.data)
     assert x.is_contiguous()
     return C.c_void_p(x.data_ptr())
+
+
+def _ks(keyset):
+    """handle of a KeySet, or NULL = the context's default set"""
+    return keyset.h if keyset is not None else C.c_void_p(0)
+
+
+class KeySet:
+    """One seal::RelinKeys / seal::GaloisKeys object on the device (hhe_keyset): keys with identity."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.hhe_keyset_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.hhe_keyset_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_relin(self, ksk):
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        assert ksk.shape == (self.ctx.L, 2, self.ctx.K, self.ctx.n)
+        self.ctx._chk(self.ctx.lib.hhe_keyset_set_relin(self.h, _ptr(ksk)))
+        return self
+
+    def set_galois(self, elt, ksk):
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
+        assert ksk.shape == (self.ctx.L, 2, self.ctx.K, self.ctx.n)
+        self.ctx._chk(self.ctx.lib.hhe_keyset_set_galois(self.h, C.c_uint32(elt), _ptr(ksk)))
+        return self
+
+    def has_galois(self, elt):
+        return bool(self.ctx.lib.hhe_keyset_has_galois(self.h, C.c_uint32(elt)))
+
+    def has_relin(self):
+        return bool(self.ctx.lib.hhe_keyset_has_relin(self.h))
+
+    def seal_load_relin_keys(self, blob):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))
+        used = C.c_size_t(0)
+        self.ctx._chk(self.ctx.lib.hhe_seal_load_relin_keys_ks(self.h, buf, C.c_size_t(len(blob)), C.byref(used)))
+        return int(used.value)
+
+    def seal_load_galois_keys(self, blob):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))
+        used, cnt = C.c_size_t(0), C.c_uint32(0)
+        self.ctx._chk(self.ctx.lib.hhe_seal_load_galois_keys_ks(self.h, buf, C.c_size_t(len(blob)), C.byref(used), C.byref(cnt)))
+        return int(used.value), int(cnt.value)
 
 
 class Context:
@@ -169,26 +230,32 @@ class Context:
     def multiply_plain(self, ct, plain, out, B, bcast=False):
         self._chk(self.lib.hhe_multiply_plain(self.h, _ptr(ct), _ptr(plain), C.c_int(int(bcast)), _ptr(out), C.c_size_t(B)))
 
-    def apply_galois(self, ct, elt, out, B):
-        self._chk(self.lib.hhe_apply_galois(self.h, _ptr(ct), C.c_uint32(elt), _ptr(out), C.c_size_t(B)))
+    def keyset(self):
+        return KeySet(self)
 
-    def rotate_rows(self, ct, step, out, B):
-        self._chk(self.lib.hhe_rotate_rows(self.h, _ptr(ct), C.c_int(step), _ptr(out), C.c_size_t(B)))
+    # gk / rk: the KeySet the call names (None = the context's default set)
+    def apply_galois(self, ct, elt, out, B, gk=None):
+        self._chk(self.lib.hhe_apply_galois_ks(self.h, _ks(gk), _ptr(ct), C.c_uint32(elt), _ptr(out), C.c_size_t(B)))
 
-    def rotate_columns(self, ct, out, B):
-        self._chk(self.lib.hhe_rotate_columns(self.h, _ptr(ct), _ptr(out), C.c_size_t(B)))
+    def rotate_rows(self, ct, step, out, B, gk=None):
+        self._chk(self.lib.hhe_rotate_rows_ks(self.h, _ks(gk), _ptr(ct), C.c_int(step), _ptr(out), C.c_size_t(B)))
+
+    def rotate_columns(self, ct, out, B, gk=None):
+        self._chk(self.lib.hhe_rotate_columns_ks(self.h, _ks(gk), _ptr(ct), _ptr(out), C.c_size_t(B)))
 
     def multiply(self, a, b, out3, B):
         self._chk(self.lib.hhe_multiply(self.h, _ptr(a), _ptr(b), _ptr(out3), C.c_size_t(B)))
 
-    def relinearize(self, a3, out, B, slot=None):
-        if slot is None:
+    def relinearize(self, a3, out, B, slot=None, rk=None):
+        if rk is not None:
+            self._chk(self.lib.hhe_relinearize_ks(self.h, _ks(rk), _ptr(a3), _ptr(out), C.c_size_t(B)))
+        elif slot is None:
             self._chk(self.lib.hhe_relinearize(self.h, _ptr(a3), _ptr(out), C.c_size_t(B)))
         else:
             self._chk(self.lib.hhe_relinearize_slot(self.h, C.c_int(slot), _ptr(a3), _ptr(out), C.c_size_t(B)))
 
     # ---- hot path ----
-    def transcipher(self, enc_key, cw, ncw, block_index, out, use_bsgs=False):
+    def transcipher(self, enc_key, cw, ncw, block_index, out, use_bsgs=False, rk=None, gk=None):
         """cw: host uint64 [B][128]; ncw [B]; block_index [B]; enc_key/out device."""
         cw = np.ascontiguousarray(cw, dtype=np.uint64)
         B = cw.shape[0]
@@ -196,8 +263,8 @@ class Context:
         ncw = np.ascontiguousarray(ncw, dtype=np.uint32)
         bi = np.ascontiguousarray(block_index, dtype=np.uint64)
         assert ncw.shape == (B,) and bi.shape == (B,)
-        self._chk(self.lib.hhe_pasta3_transcipher(self.h, _ptr(enc_key), _ptr(cw), _ptr(ncw), _ptr(bi), C.c_size_t(B),
-                                                  C.c_int(int(use_bsgs)), _ptr(out)))
+        self._chk(self.lib.hhe_pasta3_transcipher_ks(self.h, _ks(rk), _ks(gk), _ptr(enc_key), _ptr(cw), _ptr(ncw), _ptr(bi), C.c_size_t(B),
+                                                     C.c_int(int(use_bsgs)), _ptr(out)))
 
     def clear_block_cache(self):
         self.lib.hhe_pasta3_clear_block_cache(self.h)
@@ -206,21 +273,24 @@ class Context:
         mv = np.ascontiguousarray(mask_vals, dtype=np.uint64)
         self._chk(self.lib.hhe_mask(self.h, _ptr(ct), _ptr(mv), C.c_size_t(len(mv)), _ptr(out), C.c_size_t(B)))
 
-    def flatten(self, blocks, nblocks, out, S):
-        self._chk(self.lib.hhe_flatten(self.h, _ptr(blocks), C.c_size_t(nblocks), _ptr(out), C.c_size_t(S)))
+    def flatten(self, blocks, nblocks, out, S, gk=None):
+        self._chk(self.lib.hhe_flatten_ks(self.h, _ks(gk), _ptr(blocks), C.c_size_t(nblocks), _ptr(out), C.c_size_t(S)))
 
-    def decompose(self, enc_key, records, out, mask_last=True):
-        """records: host uint64 [S][nwords]; out device [S][2][L][N]"""
+    def decompose(self, enc_key, records, out, mask_last=True, rk=None, gk=None, flatten_gk=None):
+        """records: host uint64 [S][nwords]; out device [S][2][L][N]; rk / gk: the PASTA_SEAL's keys, flatten_gk: the GaloisKeys of flatten"""
         rec = np.ascontiguousarray(records, dtype=np.uint64)
         S, nwords = rec.shape
-        self._chk(self.lib.hhe_decompose(self.h, _ptr(enc_key), _ptr(rec), C.c_size_t(S), C.c_size_t(nwords),
-                                         C.c_int(int(mask_last)), _ptr(out)))
+        self._chk(self.lib.hhe_decompose_ks(self.h, _ks(rk), _ks(gk), _ks(flatten_gk), _ptr(enc_key), _ptr(rec), C.c_size_t(S), C.c_size_t(nwords),
+                                            C.c_int(int(mask_last)), _ptr(out)))
 
     def set_relin_key_slot(self, slot, ksk):
         ksk = np.ascontiguousarray(ksk, dtype=np.uint64)
         self._chk(self.lib.hhe_set_relin_key_slot(self.h, C.c_int(slot), _ptr(ksk)))
 
-    def fc_row(self, vi, w, W, n_inputs, out, B, relin_slot=0, default_galois_only=True):
+    def fc_row(self, vi, w, W, n_inputs, out, B, relin_slot=0, default_galois_only=True, rk=None, gk=None):
+        if rk is not None or gk is not None:  # the key objects the CSP names (CSP.cpp:306, 312-316)
+            self._chk(self.lib.hhe_fc_row_ks(self.h, _ks(rk), _ks(gk), _ptr(vi), _ptr(w), C.c_size_t(W), C.c_size_t(n_inputs), _ptr(out), C.c_size_t(B)))
+            return
         self._chk(self.lib.hhe_fc_row(self.h, _ptr(vi), _ptr(w), C.c_size_t(W), C.c_size_t(n_inputs), C.c_int(relin_slot),
                                       C.c_int(int(default_galois_only)), _ptr(out), C.c_size_t(B)))
 

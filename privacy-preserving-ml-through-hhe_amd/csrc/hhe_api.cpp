@@ -11,6 +11,9 @@
 namespace {
 
 int fail(int code, const std::string &msg) { hhe_set_error(msg); return code; }
+// the fused key-switch row kernel runs when the row pass has one of its sizes AND every key-level modulus has the pseudo-Mersenne
+// form its arithmetic is written for (SEAL's own primes do); other contexts take the separate-kernel path (any N, any primes < 2^61)
+bool use_row_kernel(const hhe_ctx *c) { return k_ks_row_supported(c->logn) && ntt_lazy8(c, 0, c->K); }
 int dev_fail(const char *where) { return fail(HHE_ERR_DEVICE, std::string(where) + ": " + rt_last_error()); }
 
 int need(hhe_ctx *c, size_t B)
@@ -117,8 +120,8 @@ int ensure_key_shoup(hhe_ctx *c, const u64 *key, const u64 **out)
 // out[b] = (base ? base polys selected by mask : 0) + key-switched pair.
 // galois_einv > 0 (N >= 4096 only): d and base are the UN-rotated polynomials of a rotation; the digit loads and the base
 // fetch of the fused mod-down read them through the Galois map, so no galois_kernel launch and no rotated copy is needed
-void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, const u64 *base, size_t base_stride,
-                   int base_mask, u64 *out, size_t B, u32 galois_einv = 0)
+int op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, const u64 *base, size_t base_stride,
+                  int base_mask, u64 *out, size_t B, u32 galois_einv = 0)
 {
     const int L = c->L, K = c->K;
     NttArgs a = ntt_args(c, d, c->w->ws_T, B * L * K, 0, K);
@@ -126,8 +129,8 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
     a.store_op = STORE_LAZY;  // ks_mac reduces: digits may stay in [0,4q)
     a.load_einv = galois_einv;
     const u64 *key_s = nullptr;
-    const bool rowk = k_ks_row_supported(c->logn) && ensure_key_shoup(c, key, &key_s) == HHE_OK;
-    if (galois_einv && !rowk) { fail(HHE_ERR_DEVICE, "switch_key: Shoup table of the key could not be built"); return; }
+    const bool rowk = use_row_kernel(c) && ensure_key_shoup(c, key, &key_s) == HHE_OK;
+    if (galois_einv && !rowk) return fail(HHE_ERR_DEVICE, "switch_key: Shoup table of the key could not be built");
     if (rowk) {
         // N >= 4096: strided pass of the digit transforms, then ONE kernel for their row pass, the key inner product and
         // the inverse row pass of all 2K sums (ks_row_kernel, as in the matmul loop), then the strided inverse passes with
@@ -139,7 +142,7 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
         memset(&x, 0, sizeof(x));
         x.key = key; x.key_s = key_s; x.U0 = W; x.U1 = W + (size_t)L * n; x.u_stride = (size_t)2 * L * n; x.Usp = Usp;
         x.B = (int)B; x.L = L; x.K = K;
-        k_ks_row(a, x, nullptr, c->w->stream);
+        if (k_ks_row(a, x, nullptr, c->w->stream)) return dev_fail("switch_key");
         NttArgs as = ntt_args(c, Usp, Usp, B * 2, K - 1, 1);
         as.store_op = STORE_RSP;
         k_ntt_pass(as, true, true, c->w->stream);
@@ -147,7 +150,7 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
         ad.store_op = STORE_KSF; ad.aux_r = Usp; ad.aux_in = base; ad.base_stride = base_stride; ad.base_mask = base ? base_mask : 0;
         ad.aux_out = out; ad.gal_einv = galois_einv;
         k_ntt_pass(ad, true, true, c->w->stream);
-        return;
+        return HHE_OK;
     }
     k_ntt(a, false, c->w->stream);
     KsMacArgs m;
@@ -158,12 +161,13 @@ void op_switch_key(hhe_ctx *c, const u64 *d, size_t d_stride, const u64 *key, co
     KsFinishArgs f = c->ksf;
     f.S = c->w->ws_S; f.base = base; f.base_item_stride = base_stride; f.base_mask = base ? base_mask : 0; f.out = out; f.B = (int)B;
     k_ks_finish(f, c->w->stream);
+    return HHE_OK;
 }
 
 int op_apply_galois(hhe_ctx *c, const u64 *ct, u32 elt, u64 *out, size_t B)
 {
-    auto it = c->d_gk.find(elt);
-    if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    auto it = c->gks->gk.find(elt);
+    if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     const int L = c->L;
     const size_t n = c->n;
     const u32 einv = (u32)nt_invmod(elt, 2 * n);
@@ -172,13 +176,12 @@ int op_apply_galois(hhe_ctx *c, const u64 *ct, u32 elt, u64 *out, size_t B)
         rt_d2d(c->w->ws_ct[3], ct, B * c->ct_words() * 8, c->w->stream);
         src = c->w->ws_ct[3];
     }
-    if (k_ks_row_supported(c->logn)) {
+    if (use_row_kernel(c)) {
         // N >= 4096: no rotated copies -- the digit loads read c1 and the fused mod-down reads c0 through the Galois map
         const u64 *key_s = nullptr;
         int rc = ensure_key_shoup(c, it->second, &key_s);
         if (rc) return rc;
-        op_switch_key(c, src + L * n, 2 * L * n, it->second, src, 2 * L * n, 1, out, B, einv);
-        return HHE_OK;
+        return op_switch_key(c, src + L * n, 2 * L * n, it->second, src, 2 * L * n, 1, out, B, einv);
     }
     GaloisArgs g;
     memset(&g, 0, sizeof(g));
@@ -189,8 +192,7 @@ int op_apply_galois(hhe_ctx *c, const u64 *ct, u32 elt, u64 *out, size_t B)
     k_galois(g, c->w->stream);
     g.in = src + L * n; g.out = c->w->ws_d; g.out_item_stride = L * n;
     k_galois(g, c->w->stream);
-    op_switch_key(c, c->w->ws_d, L * n, it->second, out, 2 * L * n, 1, out, B);
-    return HHE_OK;
+    return op_switch_key(c, c->w->ws_d, L * n, it->second, out, 2 * L * n, 1, out, B);
 }
 
 // Evaluator::rotate_internal (seal/evaluator.h:1234)
@@ -202,7 +204,7 @@ int op_rotate_rows(hhe_ctx *c, const u64 *ct, int step, u64 *out, size_t B)
     }
     const u32 elt = galois_elt_from_step(c, step);
     if (!elt) return fail(HHE_ERR_INVALID, "step count too large");
-    if (c->d_gk.count(elt)) return op_apply_galois(c, ct, elt, out, B);
+    if (c->gks->gk.count(elt)) return op_apply_galois(c, ct, elt, out, B);
     const std::vector<int> terms = nt_naf(step);
     if (terms.size() == 1) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     const u64 *cur = ct;
@@ -250,10 +252,9 @@ void op_multiply(hhe_ctx *c, const u64 *x, const u64 *y, u64 *out3, size_t B)
 
 int op_relinearize(hhe_ctx *c, const u64 *a3, u64 *out, size_t B)
 {
-    if (!c->d_rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
+    if (!c->rks->rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
     const size_t ln = (size_t)c->L * c->n;
-    op_switch_key(c, a3 + 2 * ln, 3 * ln, c->d_rk, a3, 3 * ln, 3, out, B);
-    return HHE_OK;
+    return op_switch_key(c, a3 + 2 * ln, 3 * ln, c->rks->rk, a3, 3 * ln, 3, out, B);
 }
 
 // ------------------------------------------------------------------ PASTA public tables
@@ -460,8 +461,8 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
         op_add(c, state, c->w->ws_ct[2], state, B, 2);
     }
     const u32 g = galois_elt_from_step(c, -1);
-    auto it = c->d_gk.find(g);
-    if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    auto it = c->gks->gk.find(g);
+    if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     const u64 *key = it->second;
     const u32 ginv = (u32)nt_invmod(g, 2 * n);
     u64 *accp0 = c->w->ws_ct[1], *accp1 = c->w->ws_ct[1] + bln;
@@ -481,7 +482,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     int cur = 0;
     // The c0 branch of step i only feeds the c0 branch of step i+1, and like the digit transforms of step i+1 it depends on
     // nothing later than the inverse transforms of step i: it is held back (k5) and launched in the grids of step i+1.
-    const bool rowk = k_ks_row_supported(c->logn);
+    const bool rowk = use_row_kernel(c);
     const size_t pdiag_words = (size_t)(PASTA_R + 1) * PASTA_T * ln;  // the Shoup quotients of pdiag follow the table (ensure_block)
     const u64 *key_s = nullptr;
     if (rowk) {
@@ -495,7 +496,6 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
         NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
         a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
         a.store_op = STORE_LAZY;
-        if (c->strided_nofold && a.lazy8) a.lazy8 = 2;
         return a;
     };
     // N >= 4096 -- four launches per step: strided pass of the digit transforms (+ the held-back c0 branch's strided pass in
@@ -503,6 +503,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
     // tiles; S_0 alternates between the two halves of ws_S, so that branch reads the previous step's while this step's is
     // written); strided inverse pass of the special limbs (r_k = INTT(S_k[special]) + floor(q_sp/2)); strided inverse pass
     // of the c1 limbs with the mod-down epilogue and the Galois map (the next digits' source)
+    int krc = 0;
     auto step_row_kernel = [&](int i, size_t shift) {
         const NttArgs a = digit_args();
         if (k5_pending) k_ntt2_fwd_first(k5, a, c->w->stream);
@@ -514,7 +515,7 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
         x.acc = accp1; x.mul_ptrs = d_pdiag_ptrs; x.mul_shift = shift; x.mul_s_off = pdiag_words;
         {
             ProfScope prof(c, *c->w, B);
-            k_ks_row(a, x, k5_pending ? &k5 : nullptr, c->w->stream);
+            krc |= k_ks_row(a, x, k5_pending ? &k5 : nullptr, c->w->stream);
         }
         k5_pending = false;
         NttArgs as = ntt_args(c, r, r, B * 2, K - 1, 1);
@@ -551,11 +552,11 @@ int matmul_diagonal_fused(hhe_ctx *c, int layer, const u64 *const *d_pdiag_ptrs,
             a.store_op = STORE_KS0; a.aux_in = c0n[cur]; a.aux_out = c0n[cur ^ 1]; a.acc = accp0;
             a.aux_r = c->w->ws_S + (rowk ? (size_t)(i & 1) * K * n : 0);
             a.mul_ptrs = d_pdiag_ptrs; a.mul_shift = shift; a.gal_elt = g; a.mul_s_off = pdiag_words;
-            if (c->strided_nofold && a.lazy8) a.lazy8 = 2;  // LOAD_RNEG inputs are canonical
             k5 = a; k5_pending = true;  // launched in the grid of the next step's digit transforms
         }
         cur ^= 1;
     }
+    if (krc) return dev_fail("matmul: key-switch row kernel");
     if (k5_pending) k_ntt(k5, false, c->w->stream);
     const size_t shift = ((size_t)layer * PASTA_T + (PASTA_T - 1)) * ln;
     {   // last state: products only (a "virtual" rotation keeps the frame uniform)
@@ -641,27 +642,43 @@ extern "C" int hhe_multiply_plain(hhe_ctx *c, const uint64_t *ct, const uint64_t
     }
     return HHE_OK;
 }
-extern "C" int hhe_apply_galois(hhe_ctx *c, const uint64_t *ct, uint32_t elt, uint64_t *out, size_t B)
+// a key set handed to an entry point must belong to the context it is used with
+static int check_sets(const hhe_ctx *c, const hhe_keyset *a, const hhe_keyset *b = nullptr, const hhe_keyset *d = nullptr)
+{
+    for (const hhe_keyset *ks : {a, b, d})
+        if (ks && ks->ctx != c) return fail(HHE_ERR_INVALID, "key set belongs to another context");
+    return HHE_OK;
+}
+extern "C" int hhe_apply_galois_ks(hhe_ctx *c, const hhe_keyset *gk, const uint64_t *ct, uint32_t elt, uint64_t *out, size_t B)
 {
     HHE_LOCK(c);
     int rc = need(c, B);
-    if (rc) return rc;
+    if (rc || (rc = check_sets(c, gk))) return rc;
+    if (!ct || !out) return fail(HHE_ERR_INVALID, "hhe_apply_galois: null argument");
+    KeyScope keys(c, gk, nullptr);
     return op_apply_galois(c, ct, elt, out, B);
 }
-extern "C" int hhe_rotate_rows(hhe_ctx *c, const uint64_t *ct, int step, uint64_t *out, size_t B)
+extern "C" int hhe_apply_galois(hhe_ctx *c, const uint64_t *ct, uint32_t elt, uint64_t *out, size_t B) { return hhe_apply_galois_ks(c, nullptr, ct, elt, out, B); }
+extern "C" int hhe_rotate_rows_ks(hhe_ctx *c, const hhe_keyset *gk, const uint64_t *ct, int step, uint64_t *out, size_t B)
 {
     HHE_LOCK(c);
     int rc = need(c, B);
-    if (rc) return rc;
+    if (rc || (rc = check_sets(c, gk))) return rc;
+    if (!ct || !out) return fail(HHE_ERR_INVALID, "hhe_rotate_rows: null argument");
+    KeyScope keys(c, gk, nullptr);
     return op_rotate_rows(c, ct, step, out, B);
 }
-extern "C" int hhe_rotate_columns(hhe_ctx *c, const uint64_t *ct, uint64_t *out, size_t B)
+extern "C" int hhe_rotate_rows(hhe_ctx *c, const uint64_t *ct, int step, uint64_t *out, size_t B) { return hhe_rotate_rows_ks(c, nullptr, ct, step, out, B); }
+extern "C" int hhe_rotate_columns_ks(hhe_ctx *c, const hhe_keyset *gk, const uint64_t *ct, uint64_t *out, size_t B)
 {
     HHE_LOCK(c);
     int rc = need(c, B);
-    if (rc) return rc;
+    if (rc || (rc = check_sets(c, gk))) return rc;
+    if (!ct || !out) return fail(HHE_ERR_INVALID, "hhe_rotate_columns: null argument");
+    KeyScope keys(c, gk, nullptr);
     return op_apply_galois(c, ct, (u32)(2 * c->n - 1), out, B);
 }
+extern "C" int hhe_rotate_columns(hhe_ctx *c, const uint64_t *ct, uint64_t *out, size_t B) { return hhe_rotate_columns_ks(c, nullptr, ct, out, B); }
 extern "C" int hhe_multiply(hhe_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out3, size_t B)
 {
     HHE_LOCK(c);
@@ -670,25 +687,25 @@ extern "C" int hhe_multiply(hhe_ctx *c, const uint64_t *a, const uint64_t *b, ui
     op_multiply(c, a, b, out3, B);
     return HHE_OK;
 }
-extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, size_t B)
+extern "C" int hhe_relinearize_ks(hhe_ctx *c, const hhe_keyset *rk, const uint64_t *a3, uint64_t *out, size_t B)
 {
     HHE_LOCK(c);
     int rc = need(c, B);
-    if (rc) return rc;
+    if (rc || (rc = check_sets(c, rk))) return rc;
+    if (!a3 || !out) return fail(HHE_ERR_INVALID, "hhe_relinearize: null argument");
+    KeyScope keys(c, nullptr, rk);
     return op_relinearize(c, a3, out, B);
 }
+extern "C" int hhe_relinearize(hhe_ctx *c, const uint64_t *a3, uint64_t *out, size_t B) { return hhe_relinearize_ks(c, nullptr, a3, out, B); }
 extern "C" int hhe_relinearize_slot(hhe_ctx *c, int slot, const uint64_t *a3, uint64_t *out, size_t B)
 {
     HHE_LOCK(c);
     if (!c || slot < 0 || slot >= HHE_RELIN_SLOTS) return fail(HHE_ERR_INVALID, "hhe_relinearize_slot: bad arguments");
-    if (!c->d_rk_slot[slot]) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
+    KeyScope keys(c, nullptr, c->relin_set(slot));
+    if (!c->rks->rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
     int rc = need(c, B);
     if (rc) return rc;
-    u64 *saved = c->d_rk;
-    c->d_rk = c->d_rk_slot[slot];
-    rc = op_relinearize(c, a3, out, B);
-    c->d_rk = saved;
-    return rc;
+    return op_relinearize(c, a3, out, B);
 }
 
 // one chunk of the batch on the current lane (c->w): the schedule of PASTA_SEAL::decomposition (pasta_3_seal.cpp:123-170)
@@ -735,20 +752,20 @@ static int transcipher_chunk(hhe_ctx *c, const u64 *enc_key, const u64 *const *d
     return rc;
 }
 
-extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *cw, const uint32_t *ncw,
-                                      const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
+// hhe_pasta3_transcipher with the key objects already named (c->rks / c->gks)
+static int transcipher_impl(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *cw, const uint32_t *ncw,
+                            const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
 {
-    HHE_LOCK(c);
     if (!c || !enc_key || !cw || !ncw || !block_index || !out || B == 0) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: null argument or empty batch");
     const size_t n = c->n, half = n / 2;
     // pasta_3_seal.cpp:376-377
     if ((size_t)PASTA_T * 2 != n && (size_t)PASTA_T * 4 > n) return fail(HHE_ERR_TOO_FEW_SLOTS, "too little slots for matmul implementation!");
-    if (!c->d_rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
+    if (!c->rks->rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
     for (int step : {-1, half != PASTA_T ? PASTA_T : -1, 0})
-        if (!c->d_gk.count(galois_elt_from_step(c, step))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+        if (!c->gks->gk.count(galois_elt_from_step(c, step))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     if (use_bsgs)  // add_gk_indices (:196-200): -k*BSGS_N1, k = 1..7
         for (int k = 1; k < 8; ++k)
-            if (!c->d_gk.count(galois_elt_from_step(c, -16 * k))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+            if (!c->gks->gk.count(galois_elt_from_step(c, -16 * k))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     Lane &main = c->lanes[0];
     c->w = &main;
     int rc;
@@ -807,6 +824,21 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
     if (rt_sync(main.stream) && !rc) rc = dev_fail("hhe_pasta3_transcipher");
     return rc;
 }
+extern "C" int hhe_pasta3_transcipher_ks(hhe_ctx *c, const hhe_keyset *rk, const hhe_keyset *gk, const uint64_t *enc_key, const uint64_t *cw,
+                                         const uint32_t *ncw, const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
+{
+    HHE_LOCK(c);
+    if (!c) return fail(HHE_ERR_INVALID, "hhe_pasta3_transcipher: null context");
+    int rc = check_sets(c, rk, gk);
+    if (rc) return rc;
+    KeyScope keys(c, gk, rk);
+    return transcipher_impl(c, enc_key, cw, ncw, block_index, B, use_bsgs, out);
+}
+extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *cw, const uint32_t *ncw,
+                                      const uint64_t *block_index, size_t B, int use_bsgs, uint64_t *out)
+{
+    return hhe_pasta3_transcipher_ks(c, nullptr, nullptr, enc_key, cw, ncw, block_index, B, use_bsgs, out);
+}
 
 extern "C" int hhe_mask(hhe_ctx *c, const uint64_t *ct, const uint64_t *mask_vals, size_t count, uint64_t *out, size_t B)
 {
@@ -827,9 +859,8 @@ extern "C" int hhe_mask(hhe_ctx *c, const uint64_t *ct, const uint64_t *mask_val
     return HHE_OK;
 }
 
-extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, uint64_t *out, size_t S)
+static int flatten_impl(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, uint64_t *out, size_t S)
 {
-    HHE_LOCK(c);
     if (!c || !blocks || !out || nblocks == 0) return fail(HHE_ERR_INVALID, "hhe_flatten: bad arguments");
     int rc = need(c, S);
     if (rc) return rc;
@@ -848,13 +879,24 @@ extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, u
     }
     return HHE_OK;
 }
+extern "C" int hhe_flatten_ks(hhe_ctx *c, const hhe_keyset *gk, const uint64_t *blocks, size_t nblocks, uint64_t *out, size_t S)
+{
+    HHE_LOCK(c);
+    if (!c) return fail(HHE_ERR_INVALID, "hhe_flatten: null context");
+    int rc = check_sets(c, gk);
+    if (rc) return rc;
+    KeyScope keys(c, gk, nullptr);
+    return flatten_impl(c, blocks, nblocks, out, S);
+}
+extern "C" int hhe_flatten(hhe_ctx *c, const uint64_t *blocks, size_t nblocks, uint64_t *out, size_t S) { return hhe_flatten_ks(c, nullptr, blocks, nblocks, out, S); }
 
 // BaseCSP::decompose (src/examples/CSP/CSP.cpp:235-283) / hhe_pktnn_1fc_inference (hhe_pktnn_examples.cpp:578-630) on device:
 // per record: decomposition of every 128-word block, mask of the ragged last block, flatten -- without leaving HBM.
-extern "C" int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *records, size_t S, size_t nwords,
-                             int mask_last, uint64_t *out)
+extern "C" int hhe_decompose_ks(hhe_ctx *c, const hhe_keyset *rk, const hhe_keyset *gk, const hhe_keyset *flatten_gk, const uint64_t *enc_key,
+                                const uint64_t *records, size_t S, size_t nwords, int mask_last, uint64_t *out)
 {
     HHE_LOCK(c);
+    if (c) { int rcs = check_sets(c, rk, gk, flatten_gk); if (rcs) return rcs; }
     if (!c || !enc_key || !records || !out || S == 0 || nwords == 0) return fail(HHE_ERR_INVALID, "hhe_decompose: bad arguments");
     const size_t nb = (nwords + PASTA_T - 1) / PASTA_T, rem = nwords % PASTA_T, ctw = c->ct_words();
     if (nb * PASTA_T > c->n / 2) return fail(HHE_ERR_INVALID, "hhe_decompose: record does not fit one batching row");
@@ -875,7 +917,11 @@ extern "C" int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key, const uint64_t
         c->blocks_cap = S * nb * ctw;
     }
     u64 *blocks = c->d_blocks;
-    int rc = hhe_pasta3_transcipher(c, enc_key, cw.data(), ncw.data(), bidx.data(), S * nb, 0, blocks);
+    int rc;
+    {   // PASTA_SEAL HHE(context, pk, sk, analyst rk, analyst gk).decomposition(...) (CSP.cpp:238-252)
+        KeyScope keys(c, gk, rk);
+        rc = transcipher_impl(c, enc_key, cw.data(), ncw.data(), bidx.data(), S * nb, 0, blocks);
+    }
     if (!rc && mask_last && rem) {
         // hhe_pktnn_examples.cpp:620-625: ones on the first `rem` slots (CSP.cpp:264-269 intends the same)
         if (!(rc = need(c, S))) {
@@ -891,9 +937,17 @@ extern "C" int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key, const uint64_t
             if (!rc) k_copy_items(g, st);
         }
     }
-    if (!rc) rc = hhe_flatten(c, blocks, nb, out, S);
+    if (!rc) {  // HHE.flatten(record, tmp, csp_gk) (CSP.cpp:271-278): the Galois keys the call names
+        KeyScope keys(c, flatten_gk, nullptr);
+        rc = flatten_impl(c, blocks, nb, out, S);
+    }
     if (!rc && rt_sync(c->lanes[0].stream)) rc = dev_fail("hhe_decompose");
     return rc;
+}
+extern "C" int hhe_decompose(hhe_ctx *c, const uint64_t *enc_key, const uint64_t *records, size_t S, size_t nwords,
+                             int mask_last, uint64_t *out)
+{
+    return hhe_decompose_ks(c, nullptr, nullptr, nullptr, enc_key, records, S, nwords, mask_last, out);
 }
 
 // sealhelper::encrypted_vec_sum (sealhelper.cpp:379-392) adds rotate_rows(prod, -i) for i = 1..n-1, each rotation
@@ -916,8 +970,8 @@ struct FcLeafAcc {  // sums over the leaves of the trie (DESIGN.md "FC rotation 
 // transforms per leaf; identical words because every step is exact modular arithmetic).
 int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t B)
 {
-    auto it = c->d_gk.find(elt);
-    if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    auto it = c->gks->gk.find(elt);
+    if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     const int L = c->L, K = c->K;
     const size_t n = c->n, ln = (size_t)L * n;
     GaloisArgs g;
@@ -950,8 +1004,8 @@ int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t
 // of the correction, NTT_J(s_g) * sum_{I != J} (q_I mod q_J) key_g[I][k][J], is tabulated once per Galois key.
 int fc_corr(hhe_ctx *c, u32 elt, const u64 *key, const u64 **out)
 {
-    auto it = c->d_gk_corr.find(elt);
-    if (it != c->d_gk_corr.end()) { *out = it->second; return HHE_OK; }
+    auto it = c->gks->gk_corr.find(elt);
+    if (it != c->gks->gk_corr.end()) { *out = it->second; return HHE_OK; }
     const int L = c->L, K = c->K;
     const size_t n = c->n;
     std::vector<u64> s((size_t)K * n, 0), qmod((size_t)L * K);
@@ -975,7 +1029,7 @@ int fc_corr(hhe_ctx *c, u32 elt, const u64 *key, const u64 **out)
     const int bad = rt_sync(st);  // host staging buffers and the temporaries go out of scope
     rt_free(shat); rt_free(dq);
     if (bad) { rt_free(corr); return dev_fail("fc_corr"); }
-    c->d_gk_corr[elt] = corr;
+    c->gks->gk_corr[elt] = corr;
     *out = corr;
     return HHE_OK;
 }
@@ -992,8 +1046,8 @@ void fc_parent_digits(hhe_ctx *c, const u64 *parent, u64 *tp, size_t B)
 // one child of a node from the node's shared digit transforms: leaf (sums only) or full ciphertext into `cur`
 int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const FcLeafAcc *leaf, u64 *cur, size_t B)
 {
-    auto it = c->d_gk.find(elt);
-    if (it == c->d_gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+    auto it = c->gks->gk.find(elt);
+    if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
     const u64 *corr = nullptr;
     int rc = fc_corr(c, elt, it->second, &corr);
     if (rc) return rc;
@@ -1066,16 +1120,15 @@ int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, co
 }  // namespace
 
 // one chunk on lane `ln`, enqueued asynchronously; shared = the shared-digit evaluation (raises *ln.zero_flag when it is not exact)
-static int fc_row_chunk(hhe_ctx *c, Lane &ln, bool shared, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
+static int fc_row_chunk(hhe_ctx *c, Lane &ln, bool shared, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs,
                         int default_galois_only, uint64_t *out, size_t B);
 
-extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
-                          int default_galois_only, uint64_t *out, size_t B)
+// hhe_fc_row with the key objects already named: c->rks relinearizes the product, c->gks serves the rotation sum
+static int fc_row_impl(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int default_galois_only, uint64_t *out, size_t B)
 {
-    HHE_LOCK(c);
-    if (!c || !vi || !w || !out || W == 0 || B == 0 || n_inputs == 0 || n_inputs > c->n / 2 || relin_slot < 0 || relin_slot >= HHE_RELIN_SLOTS)
+    if (!c || !vi || !w || !out || W == 0 || B == 0 || n_inputs == 0 || n_inputs > c->n / 2)
         return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
-    if (!c->d_rk_slot[relin_slot]) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
+    if (!c->rks->rk) return fail(HHE_ERR_NO_RELIN_KEY, "relinearization key not set");
     // chunks bound the key-switch working set (digit transforms per trie level); a chunk is a multiple of W so that item i
     // of a chunk still uses weight row i % W.  Chunks are independent: with more than one internal stream (HHE_STREAMS)
     // they run round-robin on the streams, as in hhe_pasta3_transcipher.
@@ -1107,7 +1160,7 @@ extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, siz
     for (size_t b0 = 0; b0 < B && !rc; b0 += per, ++idx) {
         Lane &ln = ns ? c->lanes[1 + idx % ns] : main;
         ln.zero_flag = shared ? flags + idx : nullptr;
-        rc = fc_row_chunk(c, ln, shared, vi + b0 * ctw, w, W, n_inputs, relin_slot, default_galois_only, out + b0 * ctw, std::min(per, B - b0));
+        rc = fc_row_chunk(c, ln, shared, vi + b0 * ctw, w, W, n_inputs, default_galois_only, out + b0 * ctw, std::min(per, B - b0));
     }
     for (int s = 1; s <= ns; ++s) {
         rt_event_record(c->lanes[s].ev_done, c->lanes[s].stream);
@@ -1123,14 +1176,32 @@ extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, siz
             if (h[idx] || c->fc_shared == 2) {
                 c->fc_fallbacks++;
                 main.zero_flag = nullptr;
-                rc = fc_row_chunk(c, main, false, vi + b0 * ctw, w, W, n_inputs, relin_slot, default_galois_only, out + b0 * ctw, std::min(per, B - b0));
+                rc = fc_row_chunk(c, main, false, vi + b0 * ctw, w, W, n_inputs, default_galois_only, out + b0 * ctw, std::min(per, B - b0));
             }
     }
     if (rt_sync(main.stream) && !rc) rc = dev_fail("hhe_fc_row");
     return rc;
 }
+extern "C" int hhe_fc_row_ks(hhe_ctx *c, const hhe_keyset *rk, const hhe_keyset *gk, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs,
+                             uint64_t *out, size_t B)
+{
+    HHE_LOCK(c);
+    if (!c) return fail(HHE_ERR_INVALID, "hhe_fc_row: null context");
+    int rc = check_sets(c, rk, gk);
+    if (rc) return rc;
+    KeyScope keys(c, gk, rk);
+    return fc_row_impl(c, vi, w, W, n_inputs, 0, out, B);  // the set IS the GaloisKeys object: every key it holds is visible to rotate_rows
+}
+extern "C" int hhe_fc_row(hhe_ctx *c, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
+                          int default_galois_only, uint64_t *out, size_t B)
+{
+    HHE_LOCK(c);
+    if (!c || relin_slot < 0 || relin_slot >= HHE_RELIN_SLOTS) return fail(HHE_ERR_INVALID, "hhe_fc_row: bad arguments");
+    KeyScope keys(c, nullptr, c->relin_set(relin_slot));
+    return fc_row_impl(c, vi, w, W, n_inputs, default_galois_only, out, B);
+}
 
-static int fc_row_chunk(hhe_ctx *c, Lane &lane, bool shared, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs, int relin_slot,
+static int fc_row_chunk(hhe_ctx *c, Lane &lane, bool shared, const uint64_t *vi, const uint64_t *w, size_t W, size_t n_inputs,
                         int default_galois_only, uint64_t *out, size_t B)
 {
     c->w = &lane;
@@ -1146,14 +1217,14 @@ static int fc_row_chunk(hhe_ctx *c, Lane &lane, bool shared, const uint64_t *vi,
         std::vector<int> terms;
         const u32 direct = galois_elt_from_step(c, step);
         const bool pow2 = (i & (i - 1)) == 0;
-        if (c->d_gk.count(direct) && (pow2 || !default_galois_only)) terms.push_back(step);  // has_key(elt): one key switch
+        if (c->gks->gk.count(direct) && (pow2 || !default_galois_only)) terms.push_back(step);  // has_key(elt): one key switch
         else
             for (int t : nt_naf(step))
                 if ((size_t)std::abs(t) != c->n / 2) terms.push_back(t);
-        if (terms.size() == 1 && !c->d_gk.count(galois_elt_from_step(c, terms[0]))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+        if (terms.size() == 1 && !c->gks->gk.count(galois_elt_from_step(c, terms[0]))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
         int node = 0;
         for (int t : terms) {
-            if (!c->d_gk.count(galois_elt_from_step(c, t))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+            if (!c->gks->gk.count(galois_elt_from_step(c, t))) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
             int next = -1;
             for (int kid : trie[node].kids)
                 if (trie[kid].term == t) { next = kid; break; }
@@ -1180,10 +1251,7 @@ static int fc_row_chunk(hhe_ctx *c, Lane &lane, bool shared, const uint64_t *vi,
     u64 *wb = ln.ws_ct[0], *prod = ln.ws_rot;  // depth-0 buffer holds the product
     op_elt(c, ELT_BCAST, nullptr, w, wb, B * 2 * L, 0, L, (int)(W * 2 * L));
     op_multiply(c, vi, wb, ln.ws_ct3, B);                                  // packed_enc_multiply
-    u64 *saved = c->d_rk;
-    c->d_rk = c->d_rk_slot[relin_slot];
-    rc = op_relinearize(c, ln.ws_ct3, prod, B);                            // CSP.cpp:306
-    c->d_rk = saved;
+    rc = op_relinearize(c, ln.ws_ct3, prod, B);                            // CSP.cpp:306 (the RelinKeys object the call names: c->rks)
     if (rc) return rc;
     const size_t bln = B * (size_t)L * c->n;
     // one evaluation of the rotation trie; shared = children of a node reuse the digit transforms of its c1

@@ -31,6 +31,13 @@ struct ModDev {
     const u64 *iw;         // [N][2]: inverse powers interleaved with their Shoup quotients (inverse rounds: one 16-byte load, measured 3 % faster)
     u64 nq;                // 2^64 - q.  Read from the table, so the compiler cannot rewrite "+ h * nq" back into "- h * q": the lazy
                            // product becomes one multiply-add chain and conditional subtractions become add + sign select (no borrow chains)
+    // Pseudo-Mersenne form q = 2^b - c (every prime SEAL generates descends from a power of two, seal/util/numth.h:138-139):
+    // x mod q = (x mod 2^b) + (x >> b) * c  (mod q), one shift, one mask and one v_mad_u64_u32 -- no compare, no VCC.
+    // pm_ok = 1 when 33 <= b <= 60, c < 2^32 and 2^b + 2^(64-b) c <= 2q, i.e. the fold takes ANY 64-bit value below 2q.
+    u32 pm_sh;             // b - 32: the quotient x >> b is (high word) >> pm_sh
+    u32 pm_mask;           // (1 << (b - 32)) - 1: mask of the high word
+    u32 pm_c;              // c
+    u32 pm_ok;
 };
 
 // The modulus table is written once at context creation.  Kernels read it through the CONSTANT address space: a plain global
@@ -45,6 +52,7 @@ HD ModDev mod_at(const ModDev *mods, int i)
     m.q = p->q; m.r_lo = p->r_lo; m.r_hi = p->r_hi;
     m.ninv = p->ninv; m.ninv_s = p->ninv_s; m.ninv_t = p->ninv_t; m.ninv_t_s = p->ninv_t_s;
     m.w = p->w; m.ws = p->ws; m.fw = p->fw; m.iw = p->iw; m.nq = p->nq;
+    m.pm_sh = p->pm_sh; m.pm_mask = p->pm_mask; m.pm_c = p->pm_c; m.pm_ok = p->pm_ok;
     return m;
 #else
     return mods[i];
@@ -108,8 +116,8 @@ struct NttArgs {
     u32 load_einv;     // first pass: > 0 => the source is read through a Galois map (apply_galois as a gather): elt^-1 mod 2N;
                        // negation is modulo the SOURCE limb's prime (the digit source d_I lives mod q_I whatever the transform's modulus)
     u32 *zero_flag;    // LOAD_DIGIT: set to 1 when a coefficient equals 0 (the shared-digit FC path then falls back)
-    int lazy8;         // every modulus of the launch is below 2^60: forward butterflies correct X once per register round ([0,16q) range);
-                       // 2: additionally a forward STRIDED pass folds nothing (inputs < 2q, <= 7 stages of +2q each stay below 16q)
+    int lazy8;         // every modulus of the launch has the pseudo-Mersenne form (ModDev::pm_ok, q < 2^60): the butterflies use the truncated
+                       // Shoup product (results in [0,4q)) and fold with pm_fold once per register round; values stay below 16q <= 2^64
     int digit_reduce;  // DIGIT: 1 if some q_I >= 4*q_J (else the lazy butterflies absorb the unreduced residue)
     u64 t;          // LIFT: plain modulus
     // STORE_MUL / STORE_MAC multiplier (NTT form): (mul_ptrs ? mul_ptrs[p / mul_item_polys] : mul)

@@ -135,6 +135,14 @@ static void fill_mod(ModDev &md, u64 q, int logn, u64 t, bool with_tables, u64 *
     const u128 two64 = (u128)1 << 64;
     md.r_hi = (u64)(two64 / q);
     md.r_lo = (u64)(((two64 % q) << 64) / q);
+    {   // pseudo-Mersenne form q = 2^b - c (hhe_common.h ModDev::pm_*)
+        int b = 0;
+        while (b < 64 && (q >> b)) ++b;
+        const u64 c = b < 64 ? ((u64)1 << b) - q : 0;
+        if (b >= 33 && b <= 60 && c < ((u64)1 << 32) && (u128)c * (((u128)1 << (64 - b)) + 2) <= ((u128)1 << b)) {
+            md.pm_sh = (u32)(b - 32); md.pm_mask = ((u32)1 << (b - 32)) - 1; md.pm_c = (u32)c; md.pm_ok = 1;
+        }
+    }
     if (!with_tables) return;
     const size_t n = (size_t)1 << logn;
     const u64 psi = nt_minimal_primitive_root(2 * n, q), ipsi = nt_invmod(psi, q);
@@ -212,6 +220,8 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     }
     if (rt_set_device(device)) { hhe_set_error(rt_last_error()); return HHE_ERR_DEVICE; }
     hhe_ctx *c = new hhe_ctx();
+    c->keys0.ctx = c;
+    for (auto &ks : c->rk_slots) ks.ctx = c;
     c->logn = logn; c->n = n; c->K = K; c->L = K - 1; c->t = t; c->device = device;
     c->q.assign(q, q + K);
     const int L = c->L;
@@ -228,6 +238,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     allq.insert(allq.end(), c->bsk.begin(), c->bsk.end());
     allq.push_back(t);
     std::vector<ModDev> mods(c->nmod);
+    c->pm_ok.assign(c->nmod, 0);
     std::vector<u64> host_tab((size_t)c->nmod * 6 * n);
     c->d_tables = (u64 *)rt_malloc(host_tab.size() * 8);
     c->d_mods = (ModDev *)rt_malloc(sizeof(ModDev) * c->nmod);
@@ -235,6 +246,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     for (int i = 0; i < c->nmod; ++i)
         fill_mod(mods[i], allq[i], logn, t, true, host_tab.data() + (size_t)i * 6 * n, c->d_tables + (size_t)i * 6 * n,
                  i < K ? &c->roots[i] : nullptr);
+    for (int i = 0; i < c->nmod; ++i) c->pm_ok[i] = (int)mods[i].pm_ok;
     // BatchEncoder matrix_reps_index_map
     c->slot_map.resize(n);
     {
@@ -334,9 +346,6 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
         for (int i = 0; i < L; ++i) qmax = std::max(qmax, c->q[i]);
         for (int i = 0; i < K; ++i) qmin = std::min(qmin, c->q[i]);
         c->digit_reduce = (qmax / 4 >= qmin) ? 1 : 0;
-        int n1, n2;
-        ntt_split(logn, n1, n2);
-        c->strided_nofold = (qmax / 2 < qmin && n1 <= 7 && ntt_lazy8(c, 0, K)) ? 1 : 0;
     }
     kf.mods = c->d_mods; kf.logn = logn; kf.L = L; kf.K = K;
     ap.mods = c->d_mods; ap.logn = logn; ap.L = L;
@@ -415,9 +424,9 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
         if (ln.own_stream) rt_stream_destroy(ln.stream);
     }
     rt_event_destroy(c->ev_fork);
-    for (auto &p : c->d_rk_slot) rt_free(p);
-    for (auto &kv : c->d_gk) rt_free(kv.second);
-    for (auto &kv : c->d_gk_corr) rt_free(kv.second);
+    keyset_clear(&c->keys0);
+    for (auto &ks : c->rk_slots) keyset_clear(&ks);
+    for (hhe_keyset *ks : c->sets) { keyset_clear(ks); delete ks; }  // sets the caller did not destroy
     for (auto &kv : c->d_key_shoup) rt_free(kv.second);
     rt_free(c->d_feistel_mask);
     rt_free(c->d_blocks); rt_free(c->d_flags);
@@ -509,12 +518,33 @@ extern "C" uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i)
     return 0;
 }
 
+// ------------------------------------------------------------------ key sets
+// drop what was derived from the words at `key` (its Shoup table); every stream must be done with them first
+static void forget_key(hhe_ctx *c, const u64 *key)
+{
+    auto sh = c->d_key_shoup.find(key);
+    if (sh != c->d_key_shoup.end()) { rt_free(sh->second); c->d_key_shoup.erase(sh); }
+}
+// The kernels multiply key words through Shoup quotients, which are only right for words below their prime: a key that is not
+// reduced is refused (SEAL's safe load does the same, is_data_valid_for).
+static int check_key_words(const hhe_ctx *c, const uint64_t *ksk)
+{
+    const size_t n = c->n;
+    for (size_t p = 0; p < (size_t)c->L * 2 * c->K; ++p) {
+        const u64 qj = c->q[p % c->K];
+        const uint64_t *w = ksk + p * n;
+        u64 bad = 0;
+        for (size_t i = 0; i < n; ++i) bad |= (u64)(w[i] >= qj);
+        if (bad) { hhe_set_error("key-switch key data is not reduced modulo the coefficient primes"); return HHE_ERR_INVALID; }
+    }
+    return HHE_OK;
+}
 static int upload_key(hhe_ctx *c, u64 *&slot, const uint64_t *ksk)
 {
-    if (slot) {  // the Shoup table of the words being replaced
-        auto sh = c->d_key_shoup.find(slot);
-        if (sh != c->d_key_shoup.end()) { sync_ctx(c); rt_free(sh->second); c->d_key_shoup.erase(sh); }
-    }
+    int rc = check_key_words(c, ksk);
+    if (rc) return rc;
+    sync_ctx(c);  // a resident key may still be read by work in flight on any lane
+    if (slot) forget_key(c, slot);
     if (!slot) slot = (u64 *)rt_malloc(c->ksk_words() * 8);
     if (!slot || rt_h2d(slot, ksk, c->ksk_words() * 8, c->lanes[0].stream) || rt_sync(c->lanes[0].stream)) {
         hhe_set_error(std::string("key upload failed: ") + rt_last_error());
@@ -522,26 +552,91 @@ static int upload_key(hhe_ctx *c, u64 *&slot, const uint64_t *ksk)
     }
     return HHE_OK;
 }
+int keyset_put_relin(hhe_keyset *ks, const u64 *ksk) { return upload_key(ks->ctx, ks->rk, ksk); }
+int keyset_put_galois(hhe_keyset *ks, u32 elt, const u64 *ksk)
+{
+    hhe_ctx *c = ks->ctx;
+    if (!(elt & 1) || elt >= 2 * c->n) { hhe_set_error("invalid Galois element"); return HHE_ERR_INVALID; }
+    int rc = check_key_words(c, ksk);
+    if (rc) return rc;
+    auto corr = ks->gk_corr.find(elt);  // derived from the key being replaced
+    if (corr != ks->gk_corr.end()) { sync_ctx(c); rt_free(corr->second); ks->gk_corr.erase(corr); }
+    auto it = ks->gk.find(elt);
+    u64 *slot = it == ks->gk.end() ? nullptr : it->second;
+    const bool fresh = slot == nullptr;
+    rc = upload_key(c, slot, ksk);
+    if (rc && fresh) { rt_free(slot); return rc; }  // a key that did not arrive is not registered
+    ks->gk[elt] = slot;
+    return rc;
+}
+void keyset_clear(hhe_keyset *ks)
+{
+    hhe_ctx *c = ks->ctx;
+    if (ks->rk) { forget_key(c, ks->rk); rt_free(ks->rk); ks->rk = nullptr; }
+    for (auto &kv : ks->gk) { forget_key(c, kv.second); rt_free(kv.second); }
+    for (auto &kv : ks->gk_corr) rt_free(kv.second);
+    ks->gk.clear();
+    ks->gk_corr.clear();
+}
+extern "C" int hhe_keyset_create(hhe_ctx *c, hhe_keyset **out)
+{
+    HHE_LOCK(c);
+    if (!c || !out) { hhe_set_error("hhe_keyset_create: null argument"); return HHE_ERR_INVALID; }
+    hhe_keyset *ks = new hhe_keyset();
+    ks->ctx = c;
+    c->sets.push_back(ks);
+    *out = ks;
+    return HHE_OK;
+}
+extern "C" void hhe_keyset_destroy(hhe_keyset *ks)
+{
+    if (!ks) return;
+    hhe_ctx *c = ks->ctx;
+    HHE_LOCK(c);
+    sync_ctx(c);
+    keyset_clear(ks);
+    c->sets.erase(std::remove(c->sets.begin(), c->sets.end(), ks), c->sets.end());
+    delete ks;
+}
+extern "C" int hhe_keyset_set_relin(hhe_keyset *ks, const uint64_t *ksk)
+{
+    if (!ks || !ksk) { hhe_set_error("hhe_keyset_set_relin: null argument"); return HHE_ERR_INVALID; }
+    HHE_LOCK(ks->ctx);
+    return keyset_put_relin(ks, ksk);
+}
+extern "C" int hhe_keyset_set_galois(hhe_keyset *ks, uint32_t elt, const uint64_t *ksk)
+{
+    if (!ks || !ksk) { hhe_set_error("hhe_keyset_set_galois: null argument"); return HHE_ERR_INVALID; }
+    HHE_LOCK(ks->ctx);
+    return keyset_put_galois(ks, elt, ksk);
+}
+extern "C" int hhe_keyset_has_galois(const hhe_keyset *ks, uint32_t elt)
+{
+    if (!ks) return 0;
+    HHE_LOCK(ks->ctx);
+    return ks->gk.count(elt) ? 1 : 0;
+}
+extern "C" int hhe_keyset_has_relin(const hhe_keyset *ks)
+{
+    if (!ks) return 0;
+    HHE_LOCK(ks->ctx);
+    return ks->rk ? 1 : 0;
+}
+// the context's default set (the keys PASTA_SEAL was constructed with) and its further relin slots
 extern "C" int hhe_set_relin_key_slot(hhe_ctx *c, int slot, const uint64_t *ksk)
 {
     HHE_LOCK(c);
     if (!c || !ksk || slot < 0 || slot >= HHE_RELIN_SLOTS) return HHE_ERR_INVALID;
-    int rc = upload_key(c, c->d_rk_slot[slot], ksk);
-    if (slot == 0) c->d_rk = c->d_rk_slot[0];
-    return rc;
+    return keyset_put_relin(c->relin_set(slot), ksk);
 }
 extern "C" int hhe_set_relin_key(hhe_ctx *c, const uint64_t *ksk) { HHE_LOCK(c); return hhe_set_relin_key_slot(c, 0, ksk); }
 extern "C" int hhe_set_galois_key(hhe_ctx *c, uint32_t elt, const uint64_t *ksk)
 {
     HHE_LOCK(c);
-    if (!c || !ksk || !(elt & 1) || elt >= 2 * c->n) { hhe_set_error("hhe_set_galois_key: invalid Galois element"); return HHE_ERR_INVALID; }
-    auto corr = c->d_gk_corr.find(elt);  // derived from the key being replaced
-    if (corr != c->d_gk_corr.end()) { rt_sync(c->lanes[0].stream); rt_free(corr->second); c->d_gk_corr.erase(corr); }
-
-    u64 *&slot = c->d_gk[elt];
-    return upload_key(c, slot, ksk);
+    if (!c || !ksk) { hhe_set_error("hhe_set_galois_key: null argument"); return HHE_ERR_INVALID; }
+    return keyset_put_galois(&c->keys0, elt, ksk);
 }
-extern "C" int hhe_has_galois_key(const hhe_ctx *c, uint32_t elt) { HHE_LOCK(c); return c && c->d_gk.count(elt) ? 1 : 0; }
+extern "C" int hhe_has_galois_key(const hhe_ctx *c, uint32_t elt) { HHE_LOCK(c); return c && c->keys0.gk.count(elt) ? 1 : 0; }
 
 extern "C" void *hhe_malloc(size_t bytes) { return rt_malloc(bytes); }
 extern "C" void hhe_free(void *p) { rt_free(p); }

@@ -16,6 +16,18 @@ struct BlockTables {   // public per-(nonce, block index) data of one PASTA bloc
 
 constexpr int HHE_MAX_STREAMS = 4;
 constexpr int HHE_RELIN_SLOTS = 4;
+struct hhe_ctx;
+// One seal::RelinKeys / seal::GaloisKeys object with its identity: the reference's CSP holds several made by the same key
+// generator with different randomness (analyst_he_gk with all default elements, csp_he_gk with the flatten steps, two RelinKeys;
+// Analyst.cpp:62-94) and names the one it uses at every call (CSP.cpp:238-242, 271-278, 306, 312-316); which keys a rotation
+// finds decides both its NAF decomposition and the ciphertext words.  Tables derived from a key live with the set (gk_corr) or
+// are keyed by the key's device address (hhe_ctx::d_key_shoup), so two sets never share one.
+struct hhe_keyset {
+    hhe_ctx *ctx = nullptr;
+    u64 *rk = nullptr;                 // RelinKeys::key(2): [L][2][K][N]
+    std::map<u32, u64 *> gk;           // by Galois element: [L][2][K][N] each
+    std::map<u32, u64 *> gk_corr;      // per Galois key of THIS set: shared-digit correction [2][K][N] (KsCorrArgs), built on first FC use
+};
 struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `cap` ciphertexts)
     rt_stream stream = nullptr;
     void *ev_done = nullptr;
@@ -66,8 +78,7 @@ struct hhe_ctx {
     int nmod = 0;                  // K + (L+1) + 1
     int mod_t = 0;                 // index of the plain modulus
     int digit_reduce = 1;          // 0 when every data prime is below 4x every key prime (lazy NTT input range)
-    int strided_nofold = 0;        // 1 when the matmul loop's forward strided pass needs no range fold at all (NttArgs::lazy8 = 2): inputs
-                                   // below 2q (every data prime below 2x every key prime), at most 7 stages, 16q <= 2^64
+    std::vector<int> pm_ok;        // per ModDev index: the modulus has the pseudo-Mersenne form the lazy butterflies fold with (ModDev::pm_ok)
     u64 fc_fallbacks = 0;          // how often the shared-digit path had to be recomputed exactly
     int fc_shared = 1;             // FC rotation trie: children of a node share the digit transforms of its c1 (HHE_FC_SHARED; 2 = force the fallback, tests)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
@@ -87,12 +98,14 @@ struct hhe_ctx {
     KsFinishArgs ksf{};
     AddPlainArgs apl{};
 
-    // keys
-    u64 *d_rk = nullptr;                       // slot 0 (transciphering)
-    u64 *d_rk_slot[HHE_RELIN_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-    std::map<u32, u64 *> d_gk;
+    // keys: the default set (hhe_set_galois_key, relin slot 0) and the further relin slots are key sets owned by the context;
+    // `sets` are the ones callers created (hhe_keyset_create).  gks / rks = the sets the running entry point named (KeyScope).
+    hhe_keyset keys0;
+    hhe_keyset rk_slots[HHE_RELIN_SLOTS];      // [0] unused (slot 0 is keys0.rk)
+    std::vector<hhe_keyset *> sets;
+    hhe_keyset *gks = &keys0, *rks = &keys0;
     std::map<const u64 *, u64 *> d_key_shoup;  // per key-switch key (by device address): Shoup quotients of its words (fused row kernel), built on first use
-    std::map<u32, u64 *> d_gk_corr;            // per Galois key: shared-digit correction [2][K][N] (KsCorrArgs), built on first FC use
+    hhe_keyset *relin_set(int slot) { return slot == 0 ? &keys0 : &rk_slots[slot]; }
 
     // grow-only device scratch of hhe_decompose (all blocks of the records) and hhe_fc_row (per-chunk flags)
     u64 *d_blocks = nullptr;
@@ -130,14 +143,13 @@ u32 galois_elt_from_step(const hhe_ctx *c, int step);
 // PASTA-3 public randomness (hhe_pasta_public.cpp)
 void pasta3_block_randomness(u64 t, u64 nonce, u64 block, u64 *mats, u64 *rcs);
 
-// 1 when every modulus of an NTT launch over ModDev indices [mod_base, mod_base + mod_cycle) is below 2^60 (16q fits 64 bits):
-// the kernels may then fold the butterfly ranges once per register round (NttArgs::lazy8)
+// 1 when every modulus of an NTT launch over ModDev indices [mod_base, mod_base + mod_cycle) has the pseudo-Mersenne form
+// q = 2^b - c, 33 <= b <= 60 (ModDev::pm_ok; SEAL's own coefficient primes do, the 61-bit BEHZ base and t = 65537 do not): the
+// kernels then use the truncated Shoup product and fold the butterfly ranges once per register round (NttArgs::lazy8)
 inline int ntt_lazy8(const hhe_ctx *c, int mod_base, int mod_cycle)
 {
-    for (int i = mod_base; i < mod_base + mod_cycle; ++i) {
-        const u64 mv = i < c->K ? c->q[i] : (i <= c->K + c->L ? c->bsk[i - c->K] : c->t);
-        if (mv >> 60) return 0;  // SEAL's own primes are at most 60 bits; the BEHZ base has 61
-    }
+    for (int i = mod_base; i < mod_base + mod_cycle; ++i)
+        if (!c->pm_ok[i]) return 0;
     return 1;
 }
 
@@ -156,6 +168,22 @@ struct CtxLock {  // null-safe scoped lock of a context (entry points check thei
     explicit CtxLock(const hhe_ctx *c) { if (c) l = std::unique_lock<std::recursive_mutex>(const_cast<hhe_ctx *>(c)->mu); }
 };
 #define HHE_LOCK(c) CtxLock hhe_lock_guard_(c)
+
+// names the key objects of one entry point for the ops below it (null = the context's default set); restored on exit
+struct KeyScope {
+    hhe_ctx *c;
+    hhe_keyset *g0, *r0;
+    KeyScope(hhe_ctx *c_, const hhe_keyset *gk, const hhe_keyset *rk) : c(c_), g0(c_->gks), r0(c_->rks)
+    {
+        c->gks = gk ? const_cast<hhe_keyset *>(gk) : &c->keys0;
+        c->rks = rk ? const_cast<hhe_keyset *>(rk) : &c->keys0;
+    }
+    ~KeyScope() { c->gks = g0; c->rks = r0; }
+};
+// upload into a set (hhe_context.cpp); words are validated against the key-level primes first
+int keyset_put_galois(hhe_keyset *ks, u32 elt, const u64 *ksk);
+int keyset_put_relin(hhe_keyset *ks, const u64 *ksk);
+void keyset_clear(hhe_keyset *ks);
 
 void hhe_set_error(const std::string &msg);
 int lane_reserve(hhe_ctx *c, Lane &ln, size_t B);

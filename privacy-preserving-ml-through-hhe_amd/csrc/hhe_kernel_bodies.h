@@ -231,21 +231,23 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 }
 
 // one register round: RHO stages starting at local stage S0 of a 2^LOGM transform.
-// Forward (CT) butterflies X' = X + wY, Y' = X - wY + 2q: wY comes out of the Shoup product in [0,2q) for ANY 64-bit Y, so
-// only the additive X chain grows, by 2q per stage.  Harvey's schedule folds X back below 2q at every stage ([0,4q)
-// invariant).  LAZY8 (all moduli of the launch < 2^60, i.e. 16q <= 2^64): fold once per round instead -- X >= 8q ? X - 8q
-// at the round's first stage, then up to four stages grow it to < 16q, which still fits 64 bits.  Saves RHO-1 of every RHO
-// conditional subtractions; the values stay congruent, so every fully reduced result is unchanged.
+// Forward (CT) butterflies X' = X + wY, Y' = X - wY + kq.  Harvey's schedule (LAZY8 = false, any modulus below 2^61): wY leaves
+// the Shoup product in [0,2q) for ANY 64-bit Y, X is folded below 2q at every stage, [0,4q) invariant.
+// LAZY8 (every modulus of the launch has the pseudo-Mersenne form ModDev::pm_ok, so 16q <= 2^64): the product uses the
+// TRUNCATED high product (shoup_lazy_t: [0,4q) for any 64-bit Y, 4 instructions less than the exact one) and X is folded with
+// pm_fold (below 2q for ANY 64-bit value, 3 instructions, no compare) at the first stage of a round, and at the third stage of a
+// radix-16 round: a fold leaves X < 2q, every stage adds at most 4q to both outputs, so they stay below 2q + 3 * 4q = 14q < 2^64.  The values are
+// congruent to Harvey's, so every fully reduced result is unchanged.
 // TWL (row kernel, 256-point rows): the twiddles of stages 0..TWL_STAGES-1 of the tile's rows sit in LDS (ks_row_twiddle_fill)
 // and the rounds inside those stages read them there instead of from the global tables.
 constexpr int TWL_STAGES = 6;                                 // the first two radix-8 rounds of NttSched<8, 512>
 constexpr int TWL_ROW = (1 << TWL_STAGES) + 1;                // pairs per row: heap index 2^s + block, one pad pair (rows on distinct 16-byte slots)
-template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS, bool FW16 = false, bool TWL = false, bool NOFOLD = false>
+template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS, bool FW16 = false, bool TWL = false>
 HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, const u64 *twl = nullptr)
 {
     const NttGeom g = ntt_geom<(CC >= 0 ? LOGM : -1), CC>(a, bx, by);
     const ModDev m = mod_at_u(a.mods, g.mod_index);
-    const u64 q = m.q, q2 = q << 1, nq = m.nq, nq2 = nq << 1, nq8 = nq << 3;
+    const u64 q = m.q, q2 = q << 1, q4 = q << 2, nq = m.nq, nq2 = nq << 1;
     const gptr W = as_global(INVERSE ? m.iw : FW16 ? m.fw : m.w), WS = as_global(m.ws);
     constexpr int LO_BITS = LOGM - S0 - RHO;
     constexpr int RAD = 1 << RHO;
@@ -277,20 +279,26 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
                     for (int j = 0; j < half; j++) {
                         const int k0 = b * 2 * half + j, k1 = k0 + half;
                         u64 x = v[k0];
-                        if (LAZY8) { if (u == 0 && !NOFOLD) x = csub(x, nq8); }
-                        else x = csub(x, nq2);
-                        const u64 y = shoup_lazy_n(v[k1], w, ws, nq);
-                        v[k0] = x + y;
-                        v[k1] = x + q2 - y;
+                        if (LAZY8) {
+                            if (u == 0 || (RHO == 4 && u == 2)) x = pm_fold(x, m);
+                            const u64 y = shoup_lazy_t(v[k1], w, ws, nq);
+                            v[k0] = x + y;
+                            v[k1] = x + q4 - y;
+                        } else {
+                            x = csub(x, nq2);
+                            const u64 y = shoup_lazy_n(v[k1], w, ws, nq);
+                            v[k0] = x + y;
+                            v[k1] = x + q2 - y;
+                        }
                     }
                 }
             }
         } else {
-            // Inverse (GS) butterflies X' = X + Y, Y' = (X - Y) w.  The product leaves the Shoup multiplication in [0,2q) whatever
-            // its input, so only the sums grow, doubling per stage.  Harvey folds every sum back below 2q.  LAZY8 (16q <= 2^64)
-            // tracks the bound of each of the thread's values as a compile-time multiple of q (bnd[]; the butterfly pattern of a
-            // register round is fixed), folds a sum only when it would reach 16q, and restores the [0,2q) invariant once at the
-            // end of the round: 16 instead of 32 conditional subtractions per radix-16 round.
+            // Inverse (GS) butterflies X' = X + Y, Y' = (X - Y) w.  The product leaves the Shoup multiplication in [0,2q) ([0,4q) with
+            // the truncated high product) whatever its input, so only the sums grow, doubling per stage.  Harvey folds every sum
+            // back below 2q.  LAZY8 (16q <= 2^64) tracks the bound of each of the thread's values as a compile-time multiple of q
+            // (bnd[]; the butterfly pattern of a register round is fixed), folds an operand with pm_fold only when a sum would pass
+            // 16q, and restores the [0,2q) invariant once at the end of the round.
             int bnd[RAD];
 #pragma unroll
             for (int k = 0; k < RAD; k++) bnd[k] = 2;
@@ -304,21 +312,16 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
 #pragma unroll
                     for (int j = 0; j < half; j++) {
                         const int k0 = b * 2 * half + j, k1 = k0 + half;
-                        const u64 x = v[k0], y = v[k1];
-                        u64 s = x + y;
+                        u64 x = v[k0], y = v[k1];
                         if (LAZY8) {
-                            int bs = bnd[k0] + bnd[k1];
-                            if (bs >= 16) {  // x, y < 8q each
-                                s = csub(s, nq8);
-                                bs = 8;
-                            }
-                            v[k0] = s;
-                            v[k1] = shoup_lazy_n(x + q * (u64)bnd[k1] - y, w, ws, nq);  // + bnd q keeps the difference non-negative
-                            bnd[k0] = bs;
-                            bnd[k1] = 2;
+                            if (bnd[k0] + bnd[k1] > 16) { x = pm_fold(x, m); bnd[k0] = 2; }
+                            if (bnd[k0] + bnd[k1] > 16) { y = pm_fold(y, m); bnd[k1] = 2; }
+                            v[k0] = x + y;
+                            v[k1] = shoup_lazy_t(x + q * (u64)bnd[k1] - y, w, ws, nq);  // + bnd q keeps the difference non-negative; below 16q
+                            bnd[k0] = bnd[k0] + bnd[k1];
+                            bnd[k1] = 4;
                         } else {
-                            s = csub(s, nq2);
-                            v[k0] = s;
+                            v[k0] = csub(x + y, nq2);
                             v[k1] = shoup_lazy_n(x + q2 - y, w, ws, nq);
                         }
                     }
@@ -326,11 +329,8 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
             }
             if (LAZY8) {
 #pragma unroll
-                for (int k = 0; k < RAD; k++) {
-#pragma unroll
-                    for (int h = 8; h >= 2; h >>= 1)  // fold 16q -> 8q -> 4q -> 2q as far as this value's bound requires
-                        if (bnd[k] > h) v[k] = csub(v[k], nq * (u64)h);
-                }
+                for (int k = 0; k < RAD; k++)
+                    if (bnd[k] > 2) v[k] = pm_fold(v[k], m);
             }
         }
 #pragma unroll
@@ -436,11 +436,11 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
             return;
         }
     } else {
-        // forward results arrive in [0,4q), or [0,16q) from LAZY8 rounds; a Barrett product takes them as they are
+        // forward results arrive in [0,4q), or [0,14q) from LAZY8 rounds; a Barrett product takes them as they are
         if (a.store_op != STORE_MUL && a.store_op != STORE_MAC)
             for (int k = 0; k < 2; k++) {
-                if (a.lazy8) v[k] = csub(csub(v[k], m.nq << 3), m.nq << 2);
-                v[k] = csub(csub(v[k], m.nq << 1), m.nq);
+                if (a.lazy8) v[k] = csub(pm_fold(v[k], m), m.nq);
+                else v[k] = csub(csub(v[k], m.nq << 1), m.nq);
             }
         if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
             const U2 d = pre.d;
@@ -773,18 +773,47 @@ HD void ks_row_twiddle_fill(const NttArgs &a, int bx, int J, bool inverse, int t
         st2(twl + 2 * (size_t)(row * TWL_ROW + h), tw);
     }
 }
-// after the forward rounds of digit I: acc_k[pair] += T * key[I][k][J]   (Shoup product in [0,2q); sums folded below 2q
-// after every fourth digit, so they never exceed 8q < 2^64)
+// The row pass of a digit transform reads the strided pass's output as it is (no load op in a second pass): the tile of the NEXT
+// digit is requested (fetch) before the rounds and key products of the current one and written to LDS (commit) after them, so
+// the wave never waits for a tile -- 2 * KSROW_NP more live VGPRs across the phases (the truncated products made room for them)
+template <int CM, int CC>
+HD void ks_row_tile_fetch(const NttArgs &fa, int bx, int by, int tid, U2 *pf)
+{
+    const NttGeom g = ntt_geom<CM, CC>(fa, bx, by);
+    const u64 *src = fa.dst + (size_t)g.poly * g.n;
+#pragma unroll
+    for (int k = 0; k < KSROW_NP; k++) {
+        int xx, lane, gi, l0, l1;
+        ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
+        pf[k] = ld2_stream(src + gi);
+    }
+}
+template <int CM, int CC>
+HD void ks_row_tile_commit(const NttArgs &fa, int bx, int by, int tid, const U2 *pf, u64 *lds)
+{
+    const NttGeom g = ntt_geom<CM, CC>(fa, bx, by);
+#pragma unroll
+    for (int k = 0; k < KSROW_NP; k++) {
+        int xx, lane, gi, l0, l1;
+        ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
+        lds[l0] = pf[k].a;
+        lds[l1] = pf[k].b;
+    }
+}
+// after the forward rounds of digit I: acc_k[pair] += T * key[I][k][J].  The kernel only runs on pseudo-Mersenne moduli (ModDev::pm_ok,
+// 16q <= 2^64): truncated Shoup products in [0,4q), sums folded below 2q by pm_fold after every third digit, so they never
+// exceed 2q + 3 * 4q = 14q < 2^64
 template <int CM, int CC>
 HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, int J, int I, int tid, const u64 *lds, u64 *acc0, u64 *acc1)
 {
     const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
     const ModDev m = mod_at_u(fa.mods, J);
-    const u64 q = m.q, nq = m.nq, nq2 = nq << 1, nq4 = nq << 2;
+    const u64 nq = m.nq;
     const size_t kofs = (((size_t)I * 2) * x.K + J) * g.n, kstep = (size_t)x.K * g.n;
     const bool diag = x.acc && I == J;
     const gptr dptr = diag ? as_global(x.mul_ptrs[b]) + x.mul_shift + (size_t)J * g.n : as_global(nullptr);
     u64 *ap = diag ? x.acc + ((size_t)b * x.L + J) * g.n : nullptr;
+    const bool fold = (I % 3) == 2 && I != x.L - 1;   // the flush phase folds after the last digit
 #pragma unroll
     for (int k = 0; k < KSROW_NP; k++) {
         int xx, lane, gi, l0, l1;
@@ -792,28 +821,27 @@ HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, i
         const U2 k0 = ld2(x.key + kofs + gi), k0s = ld2(x.key_s + kofs + gi);
         const U2 k1 = ld2(x.key + kofs + kstep + gi), k1s = ld2(x.key_s + kofs + kstep + gi);
         const u64 v0 = lds[l0], v1 = lds[l1];
-        acc0[2 * k] += shoup_lazy_n(v0, k0.a, k0s.a, nq);
-        acc0[2 * k + 1] += shoup_lazy_n(v1, k0.b, k0s.b, nq);
-        acc1[2 * k] += shoup_lazy_n(v0, k1.a, k1s.a, nq);
-        acc1[2 * k + 1] += shoup_lazy_n(v1, k1.b, k1s.b, nq);
-        if ((I & 3) == 3) {
+        acc0[2 * k] += shoup_lazy_t(v0, k0.a, k0s.a, nq);
+        acc0[2 * k + 1] += shoup_lazy_t(v1, k0.b, k0s.b, nq);
+        acc1[2 * k] += shoup_lazy_t(v0, k1.a, k1s.a, nq);
+        acc1[2 * k + 1] += shoup_lazy_t(v1, k1.b, k1s.b, nq);
+        if (fold) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                u64 &a0 = acc0[2 * k + e], &a1 = acc1[2 * k + e];
-                a0 = csub(csub(a0, nq4), nq2);
-                a1 = csub(csub(a1, nq4), nq2);
+                acc0[2 * k + e] = pm_fold(acc0[2 * k + e], m);
+                acc1[2 * k + e] = pm_fold(acc1[2 * k + e], m);
             }
         }
         if (diag) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product (lazy input)
             const U2 d = ld2g(dptr + gi);
             U2 ac = ld2(ap + gi);
-            if (x.mul_s_off) {  // Shoup product with the table's quotients
+            if (x.mul_s_off) {  // Shoup product with the table's quotients: canonical sum + [0,4q) -> fold below 2q -> canonical
                 const U2 ds = ld2g(dptr + x.mul_s_off + gi);
-                ac.a = csub(csub(ac.a + shoup_lazy_n(v0, d.a, ds.a, nq), nq2), nq);
-                ac.b = csub(csub(ac.b + shoup_lazy_n(v1, d.b, ds.b, nq), nq2), nq);
+                ac.a = csub(pm_fold(ac.a + shoup_lazy_t(v0, d.a, ds.a, nq), m), nq);
+                ac.b = csub(pm_fold(ac.b + shoup_lazy_t(v1, d.b, ds.b, nq), m), nq);
             } else {
-                ac.a = addmod(ac.a, mulmod(v0, d.a, m), q);
-                ac.b = addmod(ac.b, mulmod(v1, d.b, m), q);
+                ac.a = addmod(ac.a, mulmod(v0, d.a, m), m.q);
+                ac.b = addmod(ac.b, mulmod(v1, d.b, m), m.q);
             }
             st2(ap + gi, ac);
         }
@@ -824,16 +852,14 @@ template <int CM, int CC>
 HD void ks_row_flush_phase(const NttArgs &fa, int bx, int J, int tid, u64 *lds, const u64 *acc, u64 *canon_out)
 {
     const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
-    const u64 nq = mod_at_u(fa.mods, J).nq, nq2 = nq << 1, nq4 = nq << 2;
+    const ModDev m = mod_at_u(fa.mods, J);
 #pragma unroll
     for (int k = 0; k < KSROW_NP; k++) {
         int xx, lane, gi, l0, l1;
         ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
-        u64 v0 = acc[2 * k], v1 = acc[2 * k + 1];
-        v0 = csub(csub(v0, nq4), nq2);
-        v1 = csub(csub(v1, nq4), nq2);
+        u64 v0 = pm_fold(acc[2 * k], m), v1 = pm_fold(acc[2 * k + 1], m);
         if (canon_out) {
-            v0 = csub(v0, nq); v1 = csub(v1, nq);
+            v0 = csub(v0, m.nq); v1 = csub(v1, m.nq);
             st2(canon_out + gi, U2{v0, v1});
         } else { lds[l0] = v0; lds[l1] = v1; }
     }

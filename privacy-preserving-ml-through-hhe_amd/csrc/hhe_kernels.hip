@@ -76,14 +76,14 @@ template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH = T, bool
 struct NttRounds {
     static constexpr int R = NttSched<LOGM, SCH>::R;
     // forward: rounds 0..R-1 ascending; inverse: descending
-    template <int I, int S0, bool LAZY8 = false, bool NOFOLD = false>
+    template <int I, int S0, bool LAZY8 = false>
     static __device__ __forceinline__ void fwd(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl)
     {
         if constexpr (I < R) {
             constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL, NOFOLD>(a, bx, by, threadIdx.x, lds, twl);
+            ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL>(a, bx, by, threadIdx.x, lds, twl);
             __syncthreads();
-            fwd<I + 1, S0 + RHO, LAZY8, NOFOLD>(a, bx, by, lds, twl);
+            fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds, twl);
         }
     }
     template <int I, int SEND, bool LAZY8 = false>
@@ -98,12 +98,15 @@ struct NttRounds {
     }
 };
 // the register rounds of one pass over the tile staged in LDS (each round ends with a barrier)
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int SCH = T, bool TWL = false>
+// PM = the caller guarantees pseudo-Mersenne moduli (the fused row kernel): only the lazy rounds are instantiated
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int SCH = T, bool TWL = false, bool PM = false>
 static __device__ __forceinline__ void ntt_tile_rounds(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl = nullptr)
 {
-    if constexpr (!INVERSE) {
-        if (STRIDED && LOGM <= 7 && a.lazy8 == 2) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, true, true>(a, bx, by, lds, twl);
-        else if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, true>(a, bx, by, lds, twl);
+    if constexpr (PM) {
+        if constexpr (!INVERSE) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, true>(a, bx, by, lds, twl);
+        else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, true>(a, bx, by, lds, twl);
+    } else if constexpr (!INVERSE) {
+        if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, true>(a, bx, by, lds, twl);
         else NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template fwd<0, 0, false>(a, bx, by, lds, twl);
     } else {
         if (a.lazy8) NttRounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>::template inv<NttSched<LOGM, SCH>::R - 1, LOGM, true>(a, bx, by, lds, twl);
@@ -112,14 +115,14 @@ static __device__ __forceinline__ void ntt_tile_rounds(const NttArgs &a, int bx,
 }
 
 // one pass of one tile: load phase, register rounds through LDS, store phase
-template <int LOGM, bool STRIDED, bool INVERSE, bool FULL, int T = NTT_THREADS, int SCH = T, int TL = NttTile::LOG, bool TWL = false>
+template <int LOGM, bool STRIDED, bool INVERSE, bool FULL, int T = NTT_THREADS, int SCH = T, int TL = NttTile::LOG, bool TWL = false, bool PM = false>
 static __device__ __forceinline__ void ntt_pass_tile(const NttArgs &a, int bx, int by, u64 *lds, u64 *twl = nullptr)
 {
     constexpr int CM = FULL ? LOGM : -1, CC = FULL ? TL - LOGM : -1;
     if constexpr (TWL) ks_row_twiddle_fill<CM, CC>(a, bx, by, INVERSE, threadIdx.x, twl);
     ntt_body_load<STRIDED, INVERSE, CM, CC, T>(a, bx, by, threadIdx.x, lds);
     __syncthreads();
-    ntt_tile_rounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL>(a, bx, by, lds, twl);
+    ntt_tile_rounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL, PM>(a, bx, by, lds, twl);
     ntt_body_store<STRIDED, INVERSE, CM, CC, T>(a, bx, by, threadIdx.x, lds);
 }
 
@@ -253,8 +256,25 @@ void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s)
 // 4 waves per SIMD.  Measured alternatives (round 2, config 2, transcipherings/s): 4096-point tiles on 256 lanes x 16 points
 // need 173+ VGPRs -- 200 at 3 waves per SIMD (spills), 237 at 2 waves per SIMD; 4096-point tiles on 512 lanes: 238.
 // The tile size (csrc/hhe_kernel_bodies.h, KSROW_TL) is now one wave's worth; the launch bound asks for 4 waves per SIMD.
+// Diagnostic build only (-DHHE_STAMPS, tools/stamps.sh; never the product): every 64th key-switch workgroup records the shader
+// clock (s_memtime) at its phase boundaries into a buffer of its own that nothing else reads -- the timeline of one wave.
+#ifdef HHE_STAMPS
+constexpr int STAMP_SLOTS = 24, STAMP_WGS = 4096;
+__device__ u64 g_ks_stamps[STAMP_WGS * STAMP_SLOTS];
+#define KS_STAMP(i) do { if (stamp_on) { const u64 t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) ((volatile u64 *)g_ks_stamps)[stamp_wg * STAMP_SLOTS + (i)] = t_; } } while (0)
+extern "C" int hhe_debug_read_stamps(u64 *out, size_t words)
+{
+    if (words > (size_t)STAMP_WGS * STAMP_SLOTS) words = (size_t)STAMP_WGS * STAMP_SLOTS;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ks_stamps), words * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define KS_STAMP(i) do { } while (0)
+#endif
+#ifndef KSROW_WAVES
+#define KSROW_WAVES 4
+#endif
 template <int LOGM>
-__global__ void __launch_bounds__(KSROW_THREADS, 4) ks_row_kernel(NttArgs a, KsRowArgs x, NttArgs c0)
+__global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_row_kernel(NttArgs a, KsRowArgs x, NttArgs c0)
 {
     // 256-point rows: the twiddles of the first two rounds of the tile's rows are staged in LDS once per direction (one
     // array: tile | twiddle heap) and serve the L digit transforms / the inverse transforms of the workgroup
@@ -267,54 +287,77 @@ __global__ void __launch_bounds__(KSROW_THREADS, 4) ks_row_kernel(NttArgs a, KsR
     // the short c0 tiles come LAST in the grid: they fill the tail behind the long key-switch workgroups (c0 first: 290.7 /s,
     // c0 last: 292.0 /s on one box; alternating the two kinds: 2 % slower than either)
     const unsigned nmain = (unsigned)(x.B * x.K) << a.tiles_log;
+#ifdef HHE_STAMPS
+    const bool stamp_on = (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < STAMP_WGS;
+    const unsigned stamp_wg = blockIdx.x >> 6;
+#endif
     if (blockIdx.x >= nmain) {
         const unsigned cb = blockIdx.x - nmain;
-        ntt_pass_tile<LOGM, false, false, true, T, SCH, KSROW_TILE_LOG, TWL>(c0, (int)(cb & ((1u << a.tiles_log) - 1)), (int)(cb >> a.tiles_log), lds, twl);
+        KS_STAMP(0);
+        ntt_pass_tile<LOGM, false, false, true, T, SCH, KSROW_TILE_LOG, TWL, true>(c0, (int)(cb & ((1u << a.tiles_log) - 1)), (int)(cb >> a.tiles_log), lds, twl);
+        KS_STAMP(16);
+        KS_STAMP(23);
         return;
     }
     const unsigned bid = blockIdx.x;
+    KS_STAMP(0);
     const int bx = (int)(bid & ((1u << a.tiles_log) - 1)), y = (int)(bid >> a.tiles_log);
     const int b = y / x.K, J = y % x.K, tid = threadIdx.x;
     const size_t n = (size_t)1 << a.logn;
     u64 acc0[2 * KSROW_NP], acc1[2 * KSROW_NP];
 #pragma unroll
     for (int k = 0; k < 2 * KSROW_NP; k++) { acc0[k] = 0; acc1[k] = 0; }
+    U2 pf[KSROW_NP];  // the tile of the next digit, in flight
+    ks_row_tile_fetch<LOGM, CC>(a, bx, (b * x.L + 0) * x.K + J, tid, pf);   // beside the twiddle fill's own loads
     if (TWL) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, false, tid, twl);
+    KS_STAMP(1);
     for (int I = 0; I < x.L; I++) {
         const int by = (b * x.L + I) * x.K + J;
-        ntt_body_load<false, false, LOGM, CC, T>(a, bx, by, tid, lds);
+        ks_row_tile_commit<LOGM, CC>(a, bx, by, tid, pf, lds);
         __syncthreads();
-        ntt_tile_rounds<LOGM, false, false, CC, T, SCH, TWL>(a, bx, by, lds, twl);
+        if (I + 1 < x.L) ks_row_tile_fetch<LOGM, CC>(a, bx, by + x.K, tid, pf);
+        KS_STAMP(2 + 3 * I);
+        ntt_tile_rounds<LOGM, false, false, CC, T, SCH, TWL, true>(a, bx, by, lds, twl);
+        KS_STAMP(3 + 3 * I);
         if (TWL && I == x.L - 1) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, tid, twl);  // behind the key products; every wave is past the forward rounds
         ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, tid, lds, acc0, acc1);
         __syncthreads();
+        KS_STAMP(4 + 3 * I);
     }
     if (J < x.L) {
         if (x.U0) {  // generic key switch: S_0[j] is inverse-transformed as well
             ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
             __syncthreads();
-            ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds, twl);
+            ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
             ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U0 + (size_t)b * x.u_stride + (size_t)J * n);
             __syncthreads();
         } else ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
+        KS_STAMP(13);
         ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
         __syncthreads();
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds, twl);
+        KS_STAMP(14);
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
+        KS_STAMP(15);
         ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U1 + (size_t)b * x.u_stride + (size_t)J * n);
     } else {
         ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
         __syncthreads();
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds, twl);
+        KS_STAMP(11);
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
+        KS_STAMP(12);
         ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 0) * n);
         __syncthreads();
+        KS_STAMP(13);
         ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
         __syncthreads();
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds, twl);
+        KS_STAMP(14);
+        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
+        KS_STAMP(15);
         ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 1) * n);
     }
+    KS_STAMP(16);
 }
-bool k_ks_row_supported(int logn) { return logn >= 12; }
-void k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s)
+int k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s)
 {
     NttArgs a = a0, c0;
     int n1, n2;
@@ -330,8 +373,9 @@ void k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_s
     case 6: hipLaunchKernelGGL((ks_row_kernel<6>), grid, dim3(KSROW_THREADS), 0, st, a, x, c0); break;
     case 7: hipLaunchKernelGGL((ks_row_kernel<7>), grid, dim3(KSROW_THREADS), 0, st, a, x, c0); break;
     case 8: hipLaunchKernelGGL((ks_row_kernel<8>), grid, dim3(KSROW_THREADS), 0, st, a, x, c0); break;
-    default: snprintf(g_rt_err, sizeof(g_rt_err), "ks_row: unsupported row pass size 2^%d", n2); break;
+    default: snprintf(g_rt_err, sizeof(g_rt_err), "ks_row: unsupported row pass size 2^%d", n2); return -1;
     }
+    return 0;
 }
 
 // ---------------------------------------------------------------- element-wise family

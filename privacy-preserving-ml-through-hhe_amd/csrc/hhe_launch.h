@@ -39,8 +39,11 @@ void k_ntt_pass(const NttArgs &a, bool inverse, bool second, rt_stream s);
 void k_ntt2_fwd_first(const NttArgs &a1, const NttArgs &a2, rt_stream s);  // first forward pass of two batches in one grid
 // fused key-switch row kernel (full 4096-point tiles only: N >= 4096); a = the digit transforms' NttArgs (dst = T);
 // c0_row (optional) = a forward transform whose second (row) pass runs in the same grid
-bool k_ks_row_supported(int logn);
-void k_ks_row(const NttArgs &a, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s);
+// supported: the row pass is 64, 128 or 256 points (N = 2^12 .. 2^16) -- the caller must also make sure that every key-level
+// modulus has the pseudo-Mersenne form (ntt_lazy8(c, 0, K)): the kernel has no other arithmetic.  k_ks_row returns 0, or -1
+// (nothing launched, rt_last_error() set) for an unsupported geometry.
+inline bool k_ks_row_supported(int logn) { const int n2 = logn - logn / 2; return logn >= 12 && n2 >= 6 && n2 <= 8; }
+int k_ks_row(const NttArgs &a, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s);
 void k_elt(const EltArgs &a, int op, rt_stream s);
 void k_copy_items(const CopyItemsArgs &a, rt_stream s);
 void k_galois(const GaloisArgs &a, rt_stream s);

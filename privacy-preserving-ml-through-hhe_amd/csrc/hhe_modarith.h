@@ -18,6 +18,28 @@ HD u64 shoup_lazy(u64 x, u64 w, u64 ws, u64 q) { return x * w - mulhi64(x, ws) *
 // the same value computed as x*w + hi*(2^64 - q): with nq taken from ModDev (opaque to the compiler) this is a v_mad_u64_u32
 // chain that can absorb one more 64-bit addend, instead of two products and a v_sub_co / v_subb_co pair
 HD u64 shoup_lazy_n(u64 x, u64 w, u64 ws, u64 nq) { return x * w + mulhi64(x, ws) * nq; }
+// Truncated high product: x1*s1 + hi32(x0*s1) + hi32(x1*s0).  It drops hi32(x0*s0) and the carries of the two middle terms'
+// low halves, so it is at most 2 below mulhi64(x, s) and never above (no overflow: (2^32-1)^2 + 2(2^32-2) < 2^64).  On gfx950
+// two v_mul_hi_u32, one v_mad_u64_u32 and one 64-bit add instead of v_mul_hi_u32 + three v_mad_u64_u32 + four register moves
+// that re-pair 32-bit halves with zeros for the 64-bit addends.
+HD u64 mulhi64_trunc(u64 x, u64 s)
+{
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), s0 = (u32)s, s1 = (u32)(s >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u64)x1 * s1 + __umulhi(x0, s1) + __umulhi(x1, s0);
+#else
+    return (u64)x1 * s1 + (u32)(((u64)x0 * s1) >> 32) + (u32)(((u64)x1 * s0) >> 32);
+#endif
+}
+// x*w mod q in [0,4q) for any x < 2^64 (the quotient estimate is at most 2 low on top of Shoup's 1)
+HD u64 shoup_lazy_t(u64 x, u64 w, u64 ws, u64 nq) { return x * w + mulhi64_trunc(x, ws) * nq; }
+// pseudo-Mersenne fold (ModDev::pm_*): congruent to x mod q and below 2^b + 2^(64-b) c <= 2q for ANY x < 2^64
+HD u64 pm_fold(u64 x, const ModDev &m)
+{
+    const u32 hi = (u32)(x >> 32);
+    const u64 r = ((u64)(hi & m.pm_mask) << 32) | (u32)x;
+    return (u64)(hi >> m.pm_sh) * m.pm_c + r;
+}
 // x >= c ? x - c : x given nc = 2^64 - c, for c <= 2^63 and x < 2c: one 64-bit add and a select on the sign of the sum
 HD u64 csub(u64 x, u64 nc)
 {

@@ -31,13 +31,13 @@ int rt_event_record(void *, rt_stream) { return 0; }
 int rt_event_sync(void *) { return 0; }
 int rt_stream_wait_event(rt_stream, void *) { return 0; }
 
-template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int S0, bool LAZY8 = false, bool TWL = false, bool NOFOLD = false>
+template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int S0, bool LAZY8 = false, bool TWL = false>
 static void rounds_fwd(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl)
 {
     if constexpr (I < NttSched<LOGM, SCH>::R) {
         constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
-        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL, NOFOLD>(a, bx, by, t, lds, twl);
-        rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, I + 1, S0 + RHO, LAZY8, TWL, NOFOLD>(a, bx, by, lds, twl);
+        for (int t = 0; t < T; t++) ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL>(a, bx, by, t, lds, twl);
+        rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, I + 1, S0 + RHO, LAZY8, TWL>(a, bx, by, lds, twl);
     }
 }
 template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH, int I, int SEND, bool LAZY8 = false, bool TWL = false>
@@ -54,8 +54,7 @@ template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T = NTT_THREADS, int
 static void tile_rounds_emu(const NttArgs &a, int bx, int by, u64 *lds, const u64 *twl = nullptr)
 {
     if constexpr (!INVERSE) {
-        if (STRIDED && LOGM <= 7 && a.lazy8 == 2) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true, TWL, true>(a, bx, by, lds, twl);
-        else if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true, TWL>(a, bx, by, lds, twl);
+        if (a.lazy8) rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, true, TWL>(a, bx, by, lds, twl);
         else rounds_fwd<LOGM, STRIDED, INVERSE, CC, T, SCH, 0, 0, false, TWL>(a, bx, by, lds, twl);
     }
     else if (a.lazy8) rounds_inv<LOGM, STRIDED, INVERSE, CC, T, SCH, NttSched<LOGM, SCH>::R - 1, LOGM, true, TWL>(a, bx, by, lds, twl);
@@ -109,7 +108,6 @@ void k_ntt_pass(const NttArgs &a, bool inverse, bool second, rt_stream)
     else { if (!second) launch_pass<false, true>(a, n2, n1); else launch_pass<true, true>(a, n1, n2); }
 }
 void k_ntt2_fwd_first(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt_pass(a1, false, false, s); k_ntt_pass(a2, false, false, s); }
-bool k_ks_row_supported(int logn) { return logn >= 12; }
 template <int LOGM>
 static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, int gx, int gy)
 {
@@ -121,6 +119,7 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
         std::vector<u64> lds(KSROW_LDS + (TWL ? KSROW_TWL : 0));
         u64 *const twl = TWL ? lds.data() + KSROW_LDS : nullptr;
         std::vector<u64> acc0((size_t)T * 2 * KSROW_NP), acc1((size_t)T * 2 * KSROW_NP);
+        std::vector<U2> pf((size_t)T * KSROW_NP);
         auto A0 = [&](int t) { return &acc0[(size_t)t * 2 * KSROW_NP]; };
         auto A1 = [&](int t) { return &acc1[(size_t)t * 2 * KSROW_NP]; };
 #pragma omp for collapse(2)
@@ -137,10 +136,12 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
                 const int b = y / x.K, J = y % x.K;
                 std::fill(acc0.begin(), acc0.end(), 0);
                 std::fill(acc1.begin(), acc1.end(), 0);
+                for (int t = 0; t < T; t++) ks_row_tile_fetch<LOGM, CC>(a, bx, (b * x.L + 0) * x.K + J, t, &pf[(size_t)t * KSROW_NP]);
                 if (TWL) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, false, t, twl);
                 for (int I = 0; I < x.L; I++) {
                     const int by = (b * x.L + I) * x.K + J;
-                    for (int t = 0; t < T; t++) ntt_body_load<false, false, LOGM, CC, T>(a, bx, by, t, lds.data());
+                    for (int t = 0; t < T; t++) ks_row_tile_commit<LOGM, CC>(a, bx, by, t, &pf[(size_t)t * KSROW_NP], lds.data());
+                    if (I + 1 < x.L) for (int t = 0; t < T; t++) ks_row_tile_fetch<LOGM, CC>(a, bx, by + x.K, t, &pf[(size_t)t * KSROW_NP]);
                     tile_rounds_emu<LOGM, false, false, CC, T, SCH, TWL>(a, bx, by, lds.data(), twl);
                     if (TWL && I == x.L - 1) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, t, twl);
                     for (int t = 0; t < T; t++) ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, t, lds.data(), A0(t), A1(t));
@@ -161,8 +162,10 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
             }
     }
 }
-void k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_stream)
+int k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_stream)
 {
+    // the device kernel only has the pseudo-Mersenne (lazy) rounds: a launch whose moduli do not qualify is a host bug
+    if (!a0.lazy8 || (c0_row && !c0_row->lazy8)) { fprintf(stderr, "emu: k_ks_row on a modulus without the pseudo-Mersenne form\n"); abort(); }
     NttArgs a = a0, c0;
     int n1, n2;
     ntt_split(a.logn, n1, n2);
@@ -175,8 +178,9 @@ void k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_s
     case 6: ks_row_emu<6>(a, x, c0, gx, gy); break;
     case 7: ks_row_emu<7>(a, x, c0, gx, gy); break;
     case 8: ks_row_emu<8>(a, x, c0, gx, gy); break;
-    default: abort();
+    default: return -1;
     }
+    return 0;
 }
 void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, false, s); k_ntt(a2, false, s); }
 void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, true, s); k_ntt(a2, true, s); }

@@ -267,3 +267,99 @@ def check_two_layer_chain(X, S, mem, n_in=24, seed=3, w1_vals=None, x_vals=None)
     if O.noise_budget(S.sk, ref1, 8) > 0:  # the first layer decrypts to the plain integer dot product (FC == matMul, hhe_pktnn_examples.cpp:692-699)
         got = int(O.decode(O.decrypt(S.sk, mem.to_host(d1)[0]))[n_in - 1])
         assert got == int(np.dot(x, w1i)) % S.t
+
+
+def check_key_sets(X, S, orc, mem, threads=True):
+    """Key objects with identity (CSP.cpp:238-242, 271-278, 306, 312-316; Analyst.cpp:62-94): two GaloisKeys objects and two
+    RelinKeys objects under ONE secret key, made with different randomness.  A = every default element (what
+    create_galois_keys() without arguments makes), B = {0, -1, 128, -128, -256, -384}.  Every call must produce the words the
+    oracle produces WITH THE SET THE CALL NAMES: rotate_rows(-384) NAF-decomposes over A and is one key switch with B; flatten
+    differs between A and B; the FC uses (rk2, A); nothing uploaded into one set is seen through another."""
+    O = S.O
+    n = O.n
+    eltsA = list(dict.fromkeys(int(e) for e in O.galois_elts_all()))
+    stepsB = [0, -1, 128, -128, -256, -384]
+    eltsB = list(dict.fromkeys(int(O.galois_elt(s)) for s in stepsB))
+    gkA = O.keygen_galois(S.sk, eltsA, 101)
+    gkB = O.keygen_galois(S.sk, eltsB, 202)   # same elements where they overlap, different randomness: different words
+    rk2 = O.keygen_relin(S.sk, 303)
+    A, Bs, R2 = X.keyset(), X.keyset(), X.keyset()
+    for e, k in zip(gkA.elts, gkA.keys):
+        A.set_galois(int(e), k)
+    for e, k in zip(gkB.elts, gkB.keys):
+        Bs.set_galois(int(e), k)
+    R2.set_relin(rk2)
+    A.set_relin(S.rk)  # a set may hold both kinds
+    assert A.has_galois(O.galois_elt(-128)) and Bs.has_galois(O.galois_elt(-384)) and not A.has_galois(O.galois_elt(-384))
+    assert R2.has_relin() and not Bs.has_relin()
+    rng = np.random.default_rng(77)
+    cts = np.stack([O.encrypt(S.pk, O.encode(rng.integers(0, O.t, n)), 70 + b) for b in range(2)])
+    d, out = mem.to_dev(cts), mem.empty(cts.shape)
+    # rotate_rows(-384): NAF over A ({128, -512} at N = 2^15; the +-N/2 term is skipped when it is a whole row), direct with B
+    refA = [O.rotate_rows(cts[b], -384, gkA) for b in range(2)]
+    refB = [O.rotate_rows(cts[b], -384, gkB) for b in range(2)]
+    assert n >= 2048 and refB[0][1] == 1 and refA[0][1] == 2   # (at N = 1024 a row has 512 slots and -384 is the element of +128)
+    X.rotate_rows(d, -384, out, 2, gk=A)
+    hA = mem.to_host(out)
+    X.rotate_rows(d, -384, out, 2, gk=Bs)
+    hB = mem.to_host(out)
+    for b in range(2):
+        assert (hA[b] == refA[b][0]).all() and (hB[b] == refB[b][0]).all()
+    assert not (hA[0] == hB[0]).all()
+    # an element both sets hold: same rotation, different key words -> different ciphertext words, each equal to its oracle
+    for ks, gk in ((A, gkA), (Bs, gkB)):
+        X.rotate_rows(d, -128, out, 2, gk=ks)
+        assert (mem.to_host(out)[1] == O.rotate_rows(cts[1], -128, gk)[0]).all()
+        X.rotate_columns(d, out, 2, gk=ks)
+        assert (mem.to_host(out)[0] == O.rotate_columns(cts[0], gk)).all()
+    # the default set is empty: the un-named call fails, and a step neither direct nor NAF-reachable in B fails with B
+    for kw in ({}, {"gk": Bs}):
+        try:
+            X.rotate_rows(d, -5, out, 2, **kw)
+            raise AssertionError("rotation without its key must fail")
+        except RuntimeError as e:
+            assert "Galois key not present" in str(e)
+    # flatten(in, out, galois_keys): 3 blocks, steps -128, -256 -- direct in B, direct in A as well but with A's words
+    blocks = np.stack([O.encrypt(S.pk, O.encode(rng.integers(0, O.t, 128)), 80 + i) for i in range(3)])
+    fo = mem.empty((1,) + O.ct_shape)
+    X.flatten(mem.to_dev(blocks[None]), 3, fo, 1, gk=A)
+    fA = mem.to_host(fo)[0]
+    X.flatten(mem.to_dev(blocks[None]), 3, fo, 1, gk=Bs)
+    fB = mem.to_host(fo)[0]
+    assert (fA == O.flatten(blocks, gkA)).all() and (fB == O.flatten(blocks, gkB)).all() and not (fA == fB).all()
+    # relinearize / FC with the objects the CSP names: csp rk (R2) and the analyst's default Galois keys (A)
+    o3 = mem.empty((2, 3) + O.ct_shape[1:])
+    X.multiply(d, d, o3, 2)
+    X.relinearize(o3, out, 2, rk=R2)
+    assert (mem.to_host(out)[0] == O.relinearize(O.multiply(cts[0], cts[0]), rk2)).all()
+    X.relinearize(o3, out, 2, rk=A)
+    assert (mem.to_host(out)[0] == O.relinearize(O.multiply(cts[0], cts[0]), S.rk)).all()
+    n_in = 45
+    v, w = rng.integers(0, 4, n_in), rng.integers(-8, 9, n_in)
+    vi, wc = O.encrypt(S.pk, O.encode(v), 91), O.encrypt(S.pk, O.encode(w % O.t), 92)
+    X.fc_row(mem.to_dev(vi[None]), mem.to_dev(wc[None]), 1, n_in, fo, 1, rk=R2, gk=A)
+    ref_fc, _ = O.fc_row(vi, wc, rk2, gkA, n_in)
+    assert (mem.to_host(fo)[0] == ref_fc).all()
+    if not threads:
+        return
+    # two request handlers at once (CSPRPC.cpp:201-203), each naming its own set on the shared context
+    import threading
+    res, errs = {}, []
+
+    def work(name, ks, step):
+        try:
+            o = mem.empty(cts.shape)
+            for _ in range(3):
+                X.rotate_rows(mem.to_dev(cts), step, o, 2, gk=ks)
+            res[name] = mem.to_host(o)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=("A", A, -128)), threading.Thread(target=work, args=("B", Bs, -128))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert (res["A"][0] == O.rotate_rows(cts[0], -128, gkA)[0]).all() and (res["B"][0] == O.rotate_rows(cts[0], -128, gkB)[0]).all()
+    for ks in (A, Bs, R2):
+        ks.close()
