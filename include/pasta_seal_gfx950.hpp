@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 #include "hhe_gfx950.h"
+#include "hhe_keyset_cache.hpp"
 
 namespace pasta {
 
@@ -49,10 +50,30 @@ public:
         if (hhe_ctx_create(logn, (int)q_.size(), q_.data(), t_, device, &h_) != HHE_OK)
             throw std::invalid_argument(std::string("encryption parameters are not set correctly: ") + hhe_last_error());
     }
-    ~HheContext() { hhe_ctx_destroy(h_); }
+    ~HheContext() { keys_.reset(); hhe_ctx_destroy(h_); }   // key sets go before their context
     HheContext(const HheContext &) = delete;
     HheContext &operator=(const HheContext &) = delete;
     hhe_ctx *handle() const { return h_; }
+    // every RelinKeys / GaloisKeys object handed to a cipher object or to a call maps to ONE device key set, found again by its
+    // contents (the reference copies the objects by value everywhere); persistent device buffers for the per-call operands
+    hhe::KeySetCache &keys() { if (!keys_) keys_.reset(new hhe::KeySetCache(h_)); return *keys_; }
+    hhe::DeviceArena &arena() { return arena_; }
+    // enc_ssk[0] arrives by value with every call (CSP.cpp:249): it crosses PCIe only when its contents change.  Caller holds the
+    // arena's lock; the resident copy lives in arena slot 2.
+    uint64_t *encrypted_key(const uint64_t *words, size_t count)
+    {
+        hhe::ContentHash hsh;
+        hsh.add(words, count);
+        uint64_t *d = arena_.get(2, count * 8);
+        if (!key_resident_ || key_hash_ < hsh || hsh < key_hash_) {
+            if (hhe_copy_h2d(h_, d, words, count * 8) != HHE_OK) throw std::runtime_error(hhe_last_error());
+            key_hash_ = hsh;
+            key_resident_ = true;
+            ++key_uploads;
+        }
+        return d;
+    }
+    uint64_t key_uploads = 0;   // instrumentation: how often an encrypted PASTA key was sent to the device
     size_t poly_modulus_degree() const { return (size_t)1 << logn_; }
     size_t data_limbs() const { return q_.size() - 1; }
     size_t ct_words() const { return 2 * data_limbs() * poly_modulus_degree(); }
@@ -63,6 +84,10 @@ private:
     std::vector<uint64_t> q_;
     uint64_t t_;
     hhe_ctx *h_ = nullptr;
+    std::unique_ptr<hhe::KeySetCache> keys_;
+    hhe::DeviceArena arena_;
+    hhe::ContentHash key_hash_;
+    bool key_resident_ = false;
 };
 
 namespace detail {
@@ -78,6 +103,14 @@ inline void check(int rc)
     default: throw std::runtime_error(msg);
     }
 }
+inline hhe_keyset *galois_set(HheContext &ctx, const GaloisKeys &gk)
+{
+    if (gk.keys.empty()) return nullptr;   // an empty object: the calls below then report "Galois key not present", as SEAL does
+    std::vector<std::pair<uint32_t, const uint64_t *>> v;
+    for (auto &kv : gk.keys) v.emplace_back(kv.first, kv.second.data());
+    return ctx.keys().galois(v, gk.keys.begin()->second.size());
+}
+inline hhe_keyset *relin_set(HheContext &ctx, const RelinKeys &rk) { return rk.key.empty() ? nullptr : ctx.keys().relin(rk.key.data(), rk.key.size()); }
 struct DevBuf {  // RAII device buffer
     void *p = nullptr;
     explicit DevBuf(size_t bytes) : p(hhe_malloc(bytes)) { if (!p) throw std::runtime_error("hhe_malloc failed"); }
@@ -94,9 +127,11 @@ public:
     SEALZpCipher(ZpCipherParams params, std::shared_ptr<HheContext> con, PublicKey pk, SecretKey sk, RelinKeys rk, GaloisKeys gk)
         : params(params), context(std::move(con)), he_pk(std::move(pk)), he_sk(std::move(sk))
     {
-        hhe_ctx *h = context->handle();
-        if (!rk.key.empty()) detail::check(hhe_set_relin_key(h, rk.key.data()));
-        for (auto &kv : gk.keys) detail::check(hhe_set_galois_key(h, kv.first, kv.second.data()));
+        // the by-value key members of the reference (SEAL_Cipher.h:28-31) become two device key sets, shared with every other cipher
+        // object that was built from the same key objects (BaseCSP::decompose builds one per request, CSP.cpp:238-242)
+        rk_set = detail::relin_set(*context, rk);
+        gk_set = detail::galois_set(*context, gk);
+        empty_set = rk_set && gk_set ? nullptr : make_empty_set();
         mod_degree = context->poly_modulus_degree();
         plain_mod = context->plain_modulus();
     }
@@ -135,19 +170,14 @@ public:
         detail::check(hhe_mask(h, d.u64(), mask_vec.data(), mask_vec.size(), d.u64(), 1));
         detail::check(hhe_copy_d2h(h, cipher.words.data(), d.p, cipher.words.size() * 8));
     }
-    // SEALZpCipher::flatten (SEAL_Cipher.cpp:170-181); uses the Galois keys held by this object
-    void flatten(std::vector<Ciphertext> &in, Ciphertext &out)
+    // SEALZpCipher::flatten(in, out, galois_keys) (SEAL_Cipher.cpp:170-181): the rotations use the GaloisKeys object the CALL names
+    // (CSP.cpp:271-278 passes csp_he_gk, not the keys the cipher object was built with)
+    void flatten(std::vector<Ciphertext> &in, Ciphertext &out, const GaloisKeys &galois_keys)
     {
-        if (in.empty()) throw std::invalid_argument("flatten: empty input");
-        const size_t w = context->ct_words();
-        detail::DevBuf d(in.size() * w * 8), o(w * 8);
-        hhe_ctx *h = context->handle();
-        for (size_t i = 0; i < in.size(); i++) detail::check(hhe_copy_h2d(h, d.u64() + i * w, in[i].words.data(), w * 8));
-        detail::check(hhe_flatten(h, d.u64(), in.size(), o.u64(), 1));
-        out.words.resize(w);
-        out.size = 2;
-        detail::check(hhe_copy_d2h(h, out.words.data(), o.p, w * 8));
+        flatten_with(in, out, or_empty(detail::galois_set(*context, galois_keys)));
     }
+    // convenience: with the Galois keys held by this object
+    void flatten(std::vector<Ciphertext> &in, Ciphertext &out) { flatten_with(in, out, or_empty(gk_set)); }
 
     // SEALZpCipher::packed_enc_mul / packed_enc_add / packed_square (SEAL_Cipher.cpp:547-566)
     void packed_enc_mul(const Ciphertext &e1, const Ciphertext &e2, Ciphertext &destination)
@@ -180,13 +210,35 @@ public:
         hhe_ctx *h = context->handle();
         detail::check(hhe_copy_h2d(h, a.p, vi.words.data(), w * 8));
         detail::check(hhe_multiply(h, a.u64(), a.u64(), o3.u64(), 1));
-        detail::check(hhe_relinearize(h, o3.u64(), a.u64(), 1));
+        detail::check(hhe_relinearize_ks(h, or_empty(rk_set), o3.u64(), a.u64(), 1));
         vo.words.resize(w);
         vo.size = 2;
         detail::check(hhe_copy_d2h(h, vo.words.data(), a.p, w * 8));
     }
 
 protected:
+    void flatten_with(std::vector<Ciphertext> &in, Ciphertext &out, const hhe_keyset *gk)
+    {
+        if (in.empty()) throw std::invalid_argument("flatten: empty input");
+        const size_t w = context->ct_words();
+        hhe_ctx *h = context->handle();
+        std::lock_guard<std::mutex> lk(context->arena().mutex());
+        uint64_t *d = context->arena().get(0, in.size() * w * 8), *o = context->arena().get(1, w * 8);
+        for (size_t i = 0; i < in.size(); i++) detail::check(hhe_copy_h2d(h, d + i * w, in[i].words.data(), w * 8));
+        detail::check(hhe_flatten_ks(h, gk, d, in.size(), o, 1));
+        out.words.resize(w);
+        out.size = 2;
+        detail::check(hhe_copy_d2h(h, out.words.data(), o, w * 8));
+    }
+    // a cipher object built WITHOUT some key must not fall through to the context's default set: an empty set of its own
+    hhe_keyset *make_empty_set()
+    {
+        hhe_keyset *ks = nullptr;
+        detail::check(hhe_keyset_create(context->handle(), &ks));
+        owned_empty.reset(ks, [](hhe_keyset *k) { hhe_keyset_destroy(k); });
+        return ks;
+    }
+    const hhe_keyset *or_empty(const hhe_keyset *ks) { return ks ? ks : (empty_set ? empty_set : (empty_set = make_empty_set())); }
     ZpCipherParams params;
     uint64_t plain_mod = 0, mod_degree = 0;
     std::vector<Ciphertext> secret_key_encrypted;
@@ -196,6 +248,10 @@ protected:
     std::vector<int> gk_indices;
     bool use_bsgs = false;
     size_t bsgs_n1 = 0, bsgs_n2 = 0;
+    // device key sets of this object's key members (owned by the context's cache); declared after `context` so that the empty set
+    // this object may own is released while its context still exists
+    hhe_keyset *rk_set = nullptr, *gk_set = nullptr, *empty_set = nullptr;
+    std::shared_ptr<hhe_keyset> owned_empty;
 };
 
 class PASTA_SEAL : public SEALZpCipher {
@@ -247,14 +303,43 @@ public:
             ncw[b] = (uint32_t)(hi - lo);
             bidx[b] = b;
         }
-        detail::DevBuf key(w * 8), out(num_block * w * 8);
         if (enc_ssk[0].words.size() != w) throw std::invalid_argument("decomposition: enc_ssk is not valid for encryption parameters");
-        detail::check(hhe_copy_h2d(h, key.p, enc_ssk[0].words.data(), w * 8));
-        detail::check(hhe_pasta3_transcipher(h, key.u64(), cw.data(), ncw.data(), bidx.data(), num_block, use_bsgs ? 1 : 0, out.u64()));
+        std::lock_guard<std::mutex> lk(context->arena().mutex());
+        uint64_t *key = context->encrypted_key(enc_ssk[0].words.data(), w), *out = context->arena().get(3, num_block * w * 8);
+        detail::check(hhe_pasta3_transcipher_ks(h, or_empty(rk_set), or_empty(gk_set), key, cw.data(), ncw.data(), bidx.data(), num_block, use_bsgs ? 1 : 0, out));
         for (size_t b = 0; b < num_block; b++) {
             res[b].words.resize(w);
             res[b].size = 2;
-            detail::check(hhe_copy_d2h(h, res[b].words.data(), out.u64() + b * w, w * 8));
+            detail::check(hhe_copy_d2h(h, res[b].words.data(), out + b * w, w * 8));
+        }
+        return res;
+    }
+
+    // BaseCSP::decompose's per-record loop (CSP.cpp:247-278) as ONE device call: decomposition of every record, the mask of the
+    // ragged last block (mask_last: as hhe_pktnn_examples.cpp:620-626; the CSP's own loop masks a copy, i.e. pass false to reproduce
+    // that) and flatten with the GaloisKeys object `flatten_gk` -- the blocks never leave HBM.  One flattened ciphertext per record.
+    std::vector<Ciphertext> decompose(const std::vector<std::vector<uint64_t>> &records, std::vector<Ciphertext> enc_ssk,
+                                      const GaloisKeys &flatten_gk, bool mask_last)
+    {
+        std::vector<Ciphertext> res(records.size());
+        if (records.empty()) return res;
+        if (enc_ssk.empty()) throw std::invalid_argument("decompose: enc_ssk is empty");
+        const size_t nwords = records[0].size(), w = context->ct_words();
+        std::vector<uint64_t> flat(records.size() * nwords);
+        for (size_t s = 0; s < records.size(); s++) {
+            if (records[s].size() != nwords) throw std::invalid_argument("decompose: records of different lengths");
+            std::copy(records[s].begin(), records[s].end(), flat.begin() + s * nwords);
+        }
+        hhe_ctx *h = context->handle();
+        std::lock_guard<std::mutex> lk(context->arena().mutex());
+        if (enc_ssk[0].words.size() != w) throw std::invalid_argument("decompose: enc_ssk is not valid for encryption parameters");
+        uint64_t *key = context->encrypted_key(enc_ssk[0].words.data(), w), *out = context->arena().get(3, records.size() * w * 8);
+        detail::check(hhe_decompose_ks(h, or_empty(rk_set), or_empty(gk_set), or_empty(detail::galois_set(*context, flatten_gk)), key, flat.data(),
+                                       records.size(), nwords, mask_last ? 1 : 0, out));
+        for (size_t s = 0; s < records.size(); s++) {
+            res[s].words.resize(w);
+            res[s].size = 2;
+            detail::check(hhe_copy_d2h(h, res[s].words.data(), out + s * w, w * 8));
         }
         return res;
     }
@@ -322,19 +407,22 @@ inline std::vector<int64_t> decrypting(const pasta::Ciphertext &enc_input, const
     return out;
 }
 
-// packed_enc_multiply + relinearize + encrypted_vec_sum for one weight row (sealhelper.cpp:268-274,379-392; CSP.cpp:306)
-inline void fc_row(pasta::HheContext &ctx, const pasta::Ciphertext &vi, const pasta::Ciphertext &w_row, size_t vec_size,
-                   pasta::Ciphertext &destination)
+// packed_enc_multiply + relinearize_inplace(.., csp_rk) + encrypted_vec_sum(.., gal_keys, n) for one weight row, with the key objects
+// the CSP names at those calls (sealhelper.cpp:268-274, 379-392; CSP.cpp:306, 312-316)
+inline void fc_row(pasta::HheContext &ctx, const pasta::Ciphertext &vi, const pasta::Ciphertext &w_row, const pasta::RelinKeys &csp_rk,
+                   const pasta::GaloisKeys &gal_keys, size_t vec_size, pasta::Ciphertext &destination)
 {
     const size_t w = ctx.ct_words();
-    pasta::detail::DevBuf a(w * 8), b(w * 8), o(w * 8);
+    hhe_keyset *rk = pasta::detail::relin_set(ctx, csp_rk), *gk = pasta::detail::galois_set(ctx, gal_keys);
+    if (!rk || !gk) throw std::invalid_argument("fc_row: empty key object");
     hhe_ctx *h = ctx.handle();
-    pasta::detail::check(hhe_copy_h2d(h, a.p, vi.words.data(), w * 8));
-    pasta::detail::check(hhe_copy_h2d(h, b.p, w_row.words.data(), w * 8));
-    pasta::detail::check(hhe_fc_row(h, a.u64(), b.u64(), 1, vec_size, 0, 1, o.u64(), 1));
-    pasta::detail::check(hhe_ctx_sync(h));
+    std::lock_guard<std::mutex> lk(ctx.arena().mutex());
+    uint64_t *a = ctx.arena().get(0, w * 8), *b = ctx.arena().get(1, w * 8), *o = ctx.arena().get(3, w * 8);
+    pasta::detail::check(hhe_copy_h2d(h, a, vi.words.data(), w * 8));
+    pasta::detail::check(hhe_copy_h2d(h, b, w_row.words.data(), w * 8));
+    pasta::detail::check(hhe_fc_row_ks(h, rk, gk, a, b, 1, vec_size, o, 1));
     destination.words.resize(w);
     destination.size = 2;
-    pasta::detail::check(hhe_copy_d2h(h, destination.words.data(), o.p, w * 8));
+    pasta::detail::check(hhe_copy_d2h(h, destination.words.data(), o, w * 8));
 }
 }  // namespace sealhelper

@@ -28,6 +28,7 @@
 #include "seal/seal.h"
 
 #include "hhe_gfx950.h"
+#include "hhe_keyset_cache.hpp"
 
 namespace pasta {
 namespace gfx950 {
@@ -55,7 +56,10 @@ struct DevBuf {  // RAII device buffer
 };
 
 // One device context per SEAL parameter set, shared by every cipher object of the process: BaseCSP::decompose builds a
-// fresh PASTA_SEAL per request (CSP.cpp:238-242), the key-switch keys stay in HBM between requests.
+// fresh PASTA_SEAL per request (CSP.cpp:238-242), the key-switch keys stay in HBM between requests.  Every RelinKeys /
+// GaloisKeys OBJECT that reaches the adapter (a constructor argument, the galois_keys of flatten, the keys of the FC calls) maps
+// to one device key set, recognised by a hash over all of its words (hhe::KeySetCache): analyst_he_gk and csp_he_gk, which
+// share elements but not words (Analyst.cpp:62-94), live side by side and every call uses the one it names.
 class DeviceContext {
 public:
     explicit DeviceContext(const seal::SEALContext &context, int device = 0)
@@ -69,7 +73,7 @@ public:
         first_parms_id_ = context.first_parms_id();
         check(hhe_ctx_create(seal::util::get_power_of_two(n_), static_cast<int>(q.size()), q.data(), t_, device, &h_));
     }
-    ~DeviceContext() { hhe_ctx_destroy(h_); }
+    ~DeviceContext() { keys_.reset(); hhe_ctx_destroy(h_); }   // key sets go before their context
     DeviceContext(const DeviceContext &) = delete;
     DeviceContext &operator=(const DeviceContext &) = delete;
 
@@ -88,32 +92,43 @@ public:
         }
         return out;
     }
-    static std::array<std::uint64_t, 4> fingerprint(const std::vector<std::uint64_t> &w)
+    // the device key set of a key object (nullptr for an empty object: the call then reports the missing key as SEAL would)
+    hhe_keyset *relin_set(const seal::RelinKeys &rk)
     {
-        return {w.size(), w.empty() ? 0 : w.front(), w.empty() ? 0 : w[w.size() / 2], w.empty() ? 0 : w.back()};
-    }
-    void upload_relin(const seal::RelinKeys &rk, int slot)
-    {
-        if (rk.data().empty() || rk.data()[0].empty()) return;
+        if (rk.data().empty() || rk.data()[0].empty()) return nullptr;
         const auto words = flatten_ksk(rk.data()[seal::RelinKeys::get_index(2)]);
-        std::lock_guard<std::mutex> lk(mu_);
-        if (relin_fp_[slot] == fingerprint(words)) return;
-        check(hhe_set_relin_key_slot(h_, slot, words.data()));
-        relin_fp_[slot] = fingerprint(words);
+        return keys().relin(words.data(), words.size());
     }
-    // every key of the object; a second upload of the same words is skipped
-    void upload_galois(const seal::GaloisKeys &gk)
+    hhe_keyset *galois_set(const seal::GaloisKeys &gk)
     {
+        std::vector<std::vector<std::uint64_t>> flat;
+        std::vector<std::pair<std::uint32_t, const std::uint64_t *>> v;
         for (std::size_t idx = 0; idx < gk.data().size(); idx++) {
             if (gk.data()[idx].empty()) continue;
-            const std::uint32_t elt = static_cast<std::uint32_t>(2 * idx + 1);  // GaloisKeys::get_index(elt) = (elt - 1) / 2
-            const auto words = flatten_ksk(gk.data()[idx]);
-            std::lock_guard<std::mutex> lk(mu_);
-            auto it = galois_fp_.find(elt);
-            if (it != galois_fp_.end() && it->second == fingerprint(words)) continue;
-            check(hhe_set_galois_key(h_, elt, words.data()));
-            galois_fp_[elt] = fingerprint(words);
+            flat.push_back(flatten_ksk(gk.data()[idx]));   // GaloisKeys::get_index(elt) = (elt - 1) / 2
+            v.emplace_back(static_cast<std::uint32_t>(2 * idx + 1), nullptr);
         }
+        if (v.empty()) return nullptr;
+        for (std::size_t i = 0; i < v.size(); i++) v[i].second = flat[i].data();
+        return keys().galois(v, flat[0].size());
+    }
+    hhe::KeySetCache &keys() { std::lock_guard<std::mutex> lk(mu_); if (!keys_) keys_.reset(new hhe::KeySetCache(h_)); return *keys_; }
+    hhe::DeviceArena &arena() { return arena_; }
+    // enc_ssk[0] arrives by value with every call (CSP.cpp:249): it crosses PCIe only when its contents change (arena slot 2;
+    // the caller holds the arena's lock)
+    std::uint64_t *encrypted_key(const seal::Ciphertext &ct)
+    {
+        if (ct.is_ntt_form() || ct.poly_modulus_degree() != n_ || ct.coeff_modulus_size() != L_ || ct.size() != 2)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        hhe::ContentHash hsh;
+        hsh.add(ct.data(), ct_words());
+        std::uint64_t *d = arena_.get(2, ct_words() * 8);
+        if (!key_resident_ || key_hash_ < hsh || hsh < key_hash_) {
+            check(hhe_copy_h2d(h_, d, ct.data(), ct_words() * 8));
+            key_hash_ = hsh;
+            key_resident_ = true;
+        }
+        return d;
     }
 
     void to_device(const seal::Ciphertext &ct, std::uint64_t *dptr) const
@@ -165,8 +180,10 @@ private:
     std::uint64_t t_ = 0;
     seal::parms_id_type first_parms_id_{};
     std::mutex mu_;
-    std::array<std::uint64_t, 4> relin_fp_[4] = {};
-    std::map<std::uint32_t, std::array<std::uint64_t, 4>> galois_fp_;
+    std::unique_ptr<hhe::KeySetCache> keys_;
+    hhe::DeviceArena arena_;
+    hhe::ContentHash key_hash_;
+    bool key_resident_ = false;
 };
 
 }  // namespace gfx950
@@ -207,6 +224,19 @@ protected:
     size_t bsgs_n2 = 0;
 
     std::shared_ptr<gfx950::DeviceContext> device;  // HBM-resident keys and tables, shared per parameter set
+    // the device key sets of he_rk / he_gk (owned by the device context's cache); an object built without a key gets an empty set of
+    // its own instead of falling through to another object's keys (declared after `device`: released while the context exists)
+    hhe_keyset *rk_set = nullptr, *gk_set = nullptr, *empty_set = nullptr;
+    std::shared_ptr<hhe_keyset> owned_empty;
+    const hhe_keyset *or_empty(const hhe_keyset *ks)
+    {
+        if (ks) return ks;
+        if (!empty_set) {
+            gfx950::check(hhe_keyset_create(device->handle(), &empty_set));
+            owned_empty.reset(empty_set, [](hhe_keyset *k) { hhe_keyset_destroy(k); });
+        }
+        return empty_set;
+    }
 
 public:
     // src/pasta/SEAL_Cipher.cpp:9-36 (all arguments by value, as the reference takes them)
@@ -219,8 +249,8 @@ public:
         encryptor.set_public_key(pk);
         mod_degree = context->first_context_data()->parms().poly_modulus_degree();
         plain_mod = context->first_context_data()->parms().plain_modulus().value();
-        device->upload_relin(he_rk, 0);
-        device->upload_galois(he_gk);
+        rk_set = device->relin_set(he_rk);
+        gk_set = device->galois_set(he_gk);
     }
     virtual ~SEALZpCipher() = default;
 
@@ -232,7 +262,7 @@ public:
     {
         for (auto &it : gk_ind) gk_indices.push_back(it);
     }
-    void create_gk() { keygen.create_galois_keys(gk_indices, he_gk); device->upload_galois(he_gk); }
+    void create_gk() { keygen.create_galois_keys(gk_indices, he_gk); gk_set = device->galois_set(he_gk); }
 
     virtual std::string get_cipher_name() const = 0;
 
@@ -268,21 +298,23 @@ public:
     // SEALZpCipher::mask (SEAL_Cipher.cpp:161-166): batch_encoder.encode(mask) + multiply_plain_inplace
     void mask(seal::Ciphertext &cipher, std::vector<uint64_t> &mask)
     {
-        gfx950::DevBuf d(device->ct_words() * 8);
-        device->to_device(cipher, d.u64());
-        gfx950::check(hhe_mask(device->handle(), d.u64(), mask.data(), mask.size(), d.u64(), 1));
-        device->from_device(*context, d.u64(), 2, cipher);
+        std::lock_guard<std::mutex> lk(device->arena().mutex());
+        std::uint64_t *d = device->arena().get(0, device->ct_words() * 8);
+        device->to_device(cipher, d);
+        gfx950::check(hhe_mask(device->handle(), d, mask.data(), mask.size(), d, 1));
+        device->from_device(*context, d, 2, cipher);
     }
     // SEALZpCipher::flatten (SEAL_Cipher.cpp:170-181): out = sum_i rotate_rows(in[i], -i * plain_size, galois_keys)
     void flatten(std::vector<seal::Ciphertext> &in, seal::Ciphertext &out, const seal::GaloisKeys &galois_keys)
     {
         if (in.empty()) throw std::invalid_argument("flatten: empty input");
-        device->upload_galois(galois_keys);
+        const hhe_keyset *gk = or_empty(device->galois_set(galois_keys));   // the GaloisKeys object THIS call names (CSP.cpp:271-278: csp_he_gk)
         const size_t w = device->ct_words();
-        gfx950::DevBuf d(in.size() * w * 8), o(w * 8);
-        for (size_t i = 0; i < in.size(); i++) device->to_device(in[i], d.u64() + i * w);
-        gfx950::check(hhe_flatten(device->handle(), d.u64(), in.size(), o.u64(), 1));
-        device->from_device(*context, o.u64(), 2, out);
+        std::lock_guard<std::mutex> lk(device->arena().mutex());
+        std::uint64_t *d = device->arena().get(0, in.size() * w * 8), *o = device->arena().get(1, w * 8);
+        for (size_t i = 0; i < in.size(); i++) device->to_device(in[i], d + i * w);
+        gfx950::check(hhe_flatten_ks(device->handle(), gk, d, in.size(), o, 1));
+        device->from_device(*context, o, 2, out);
     }
 
     // packed helpers of the FC (SEAL_Cipher.cpp:547-566)
@@ -292,7 +324,7 @@ public:
         gfx950::DevBuf a(w * 8), o3(device->ct_words(3) * 8);
         device->to_device(vi, a.u64());
         gfx950::check(hhe_multiply(device->handle(), a.u64(), a.u64(), o3.u64(), 1));
-        gfx950::check(hhe_relinearize(device->handle(), o3.u64(), a.u64(), 1));
+        gfx950::check(hhe_relinearize_ks(device->handle(), or_empty(rk_set), o3.u64(), a.u64(), 1));
         device->from_device(*context, a.u64(), 2, vo);
     }
     void packed_enc_mul(const seal::Ciphertext &encrypted1, const seal::Ciphertext &encrypted2, seal::Ciphertext &destination)
@@ -375,11 +407,36 @@ public:
             bidx[b] = b;  // pasta.init_shake(nonce, b) (:122)
         }
         const size_t w = device->ct_words();
-        gfx950::DevBuf key(w * 8), out(num_block * w * 8);
-        device->to_device(enc_ssk[0], key.u64());  // state <- enc_ssk[0] (:126)
-        gfx950::check(hhe_pasta3_transcipher(device->handle(), key.u64(), cw.data(), ncw.data(), bidx.data(), num_block,
-                                             use_bsgs ? 1 : 0, out.u64()));
-        for (size_t b = 0; b < num_block; b++) device->from_device(*context, out.u64() + b * w, 2, res[b]);
+        std::lock_guard<std::mutex> lk(device->arena().mutex());
+        std::uint64_t *key = device->encrypted_key(enc_ssk[0]);  // state <- enc_ssk[0] (:126); uploaded when its contents change
+        std::uint64_t *out = device->arena().get(3, num_block * w * 8);
+        gfx950::check(hhe_pasta3_transcipher_ks(device->handle(), or_empty(rk_set), or_empty(gk_set), key, cw.data(), ncw.data(), bidx.data(),
+                                                num_block, use_bsgs ? 1 : 0, out));
+        for (size_t b = 0; b < num_block; b++) device->from_device(*context, out + b * w, 2, res[b]);
+        return res;
+    }
+
+    // BaseCSP::decompose's per-record loop (CSP.cpp:247-278) as ONE device call: decomposition of every record, the mask of the
+    // ragged last block (mask_last: as hhe_pktnn_examples.cpp:620-626; the CSP's own loop masks a copy, i.e. pass false to reproduce
+    // that) and flatten with the GaloisKeys object `flatten_gk` -- the blocks never leave HBM.  One flattened ciphertext per record.
+    std::vector<seal::Ciphertext> decompose(const std::vector<std::vector<uint64_t>> &records, std::vector<seal::Ciphertext> enc_ssk,
+                                            const seal::GaloisKeys &flatten_gk, bool mask_last)
+    {
+        std::vector<seal::Ciphertext> res(records.size());
+        if (records.empty()) return res;
+        if (enc_ssk.empty()) throw std::invalid_argument("decompose: enc_ssk is empty");
+        const size_t nwords = records[0].size(), w = device->ct_words();
+        std::vector<uint64_t> flat(records.size() * nwords);
+        for (size_t s = 0; s < records.size(); s++) {
+            if (records[s].size() != nwords) throw std::invalid_argument("decompose: records of different lengths");
+            std::copy(records[s].begin(), records[s].end(), flat.begin() + s * nwords);
+        }
+        const hhe_keyset *fgk = or_empty(device->galois_set(flatten_gk));
+        std::lock_guard<std::mutex> lk(device->arena().mutex());
+        std::uint64_t *key = device->encrypted_key(enc_ssk[0]), *out = device->arena().get(3, records.size() * w * 8);
+        gfx950::check(hhe_decompose_ks(device->handle(), or_empty(rk_set), or_empty(gk_set), fgk, key, flat.data(), records.size(), nwords,
+                                       mask_last ? 1 : 0, out));
+        for (size_t s = 0; s < records.size(); s++) device->from_device(*context, out + s * w, 2, res[s]);
         return res;
     }
 
@@ -436,16 +493,17 @@ inline void packed_enc_multiply(const seal::Ciphertext &encrypted1, const seal::
     pasta::gfx950::check(hhe_copy_d2h(dev->handle(), destination.data(), o3.u64(), dev->ct_words(3) * 8));
 }
 
-// Evaluator::relinearize_inplace(record, csp_rk) as the CSP calls it between the two (CSP.cpp:306), on the device.  The
-// CSP's RelinKeys object lives in slot 1 (slot 0 holds the key PASTA_SEAL was constructed with).
-inline void relinearize_inplace(seal::Ciphertext &encrypted, const seal::RelinKeys &relin_keys, int relin_slot = 1)
+// Evaluator::relinearize_inplace(record, csp_rk) as the CSP calls it between the two (CSP.cpp:306), on the device, with the
+// RelinKeys object the call names (its key set is uploaded the first time the object is seen).
+inline void relinearize_inplace(seal::Ciphertext &encrypted, const seal::RelinKeys &relin_keys)
 {
     auto dev = pasta::gfx950::DeviceContext::find(encrypted.parms_id());
-    dev->upload_relin(relin_keys, relin_slot);
+    hhe_keyset *rk = dev->relin_set(relin_keys);
+    if (!rk) throw std::invalid_argument("relin_keys is not valid for encryption parameters");
     pasta::gfx950::DevBuf a3(dev->ct_words(3) * 8), o(dev->ct_words() * 8);
     if (encrypted.size() != 3) throw std::invalid_argument("encrypted is not valid for encryption parameters");
     pasta::gfx950::check(hhe_copy_h2d(dev->handle(), a3.u64(), encrypted.data(), dev->ct_words(3) * 8));
-    pasta::gfx950::check(hhe_relinearize_slot(dev->handle(), relin_slot, a3.u64(), o.u64(), 1));
+    pasta::gfx950::check(hhe_relinearize_ks(dev->handle(), rk, a3.u64(), o.u64(), 1));
     encrypted.resize(2);
     pasta::gfx950::check(hhe_copy_d2h(dev->handle(), encrypted.data(), o.u64(), dev->ct_words() * 8));
 }
@@ -455,14 +513,15 @@ inline void encrypted_vec_sum(const seal::Ciphertext &encrypted_inp, seal::Ciphe
 {
     (void)evaluator;
     auto dev = pasta::gfx950::DeviceContext::find(encrypted_inp.parms_id());
-    dev->upload_galois(gal_keys);
+    hhe_keyset *gk = dev->galois_set(gal_keys);
+    if (!gk) throw std::invalid_argument("Galois key not present");
     const size_t w = dev->ct_words();
     pasta::gfx950::DevBuf in(w * 8), acc(w * 8), rot(w * 8);
     dev->to_device(encrypted_inp, in.u64());
     // destination = encrypted_inp; for i = -1 .. -(vec_size-1): destination += rotate_rows(encrypted_inp, i)  (sealhelper.cpp:385-391)
-    pasta::gfx950::check(hhe_rotate_rows(dev->handle(), in.u64(), 0, acc.u64(), 1));  // step 0: a copy, as in SEAL
+    pasta::gfx950::check(hhe_rotate_rows_ks(dev->handle(), gk, in.u64(), 0, acc.u64(), 1));  // step 0: a copy, as in SEAL
     for (size_t i = 1; i < vec_size; i++) {
-        pasta::gfx950::check(hhe_rotate_rows(dev->handle(), in.u64(), -static_cast<int>(i), rot.u64(), 1));
+        pasta::gfx950::check(hhe_rotate_rows_ks(dev->handle(), gk, in.u64(), -static_cast<int>(i), rot.u64(), 1));
         pasta::gfx950::check(hhe_add(dev->handle(), acc.u64(), rot.u64(), acc.u64(), 1, 2));
     }
     destination = encrypted_inp;
@@ -475,15 +534,16 @@ inline void fc_row(const seal::Ciphertext &vi, const seal::Ciphertext &w_row, co
                    size_t vec_size, seal::Ciphertext &destination)
 {
     auto dev = pasta::gfx950::DeviceContext::find(vi.parms_id());
-    dev->upload_relin(csp_rk, 1);
-    dev->upload_galois(gal_keys);
+    hhe_keyset *rk = dev->relin_set(csp_rk), *gk = dev->galois_set(gal_keys);
+    if (!rk || !gk) throw std::invalid_argument("fc_row: empty key object");
     const size_t w = dev->ct_words();
-    pasta::gfx950::DevBuf a(w * 8), b(w * 8), o(w * 8);
-    dev->to_device(vi, a.u64());
-    dev->to_device(w_row, b.u64());
-    pasta::gfx950::check(hhe_fc_row(dev->handle(), a.u64(), b.u64(), 1, vec_size, 1, 1, o.u64(), 1));
+    std::lock_guard<std::mutex> lk(dev->arena().mutex());
+    std::uint64_t *a = dev->arena().get(0, w * 8), *b = dev->arena().get(1, w * 8), *o = dev->arena().get(3, w * 8);
+    dev->to_device(vi, a);
+    dev->to_device(w_row, b);
+    pasta::gfx950::check(hhe_fc_row_ks(dev->handle(), rk, gk, a, b, 1, vec_size, o, 1));
     destination = vi;
-    pasta::gfx950::check(hhe_copy_d2h(dev->handle(), destination.data(), o.u64(), w * 8));
+    pasta::gfx950::check(hhe_copy_d2h(dev->handle(), destination.data(), o, w * 8));
 }
 
 }  // namespace sealhelper

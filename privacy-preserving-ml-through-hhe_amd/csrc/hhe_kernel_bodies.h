@@ -241,7 +241,8 @@ HD void ntt_body_load(const NttArgs &a, int bx, int by, int tid, u64 *lds)
 // TWL (row kernel, 256-point rows): the twiddles of stages 0..TWL_STAGES-1 of the tile's rows sit in LDS (ks_row_twiddle_fill)
 // and the rounds inside those stages read them there instead of from the global tables.
 constexpr int TWL_STAGES = 6;                                 // the first two radix-8 rounds of NttSched<8, 512>
-constexpr int TWL_ROW = (1 << TWL_STAGES) + 1;                // pairs per row: heap index 2^s + block, one pad pair (rows on distinct 16-byte slots)
+constexpr int TWL_ROW = (1 << TWL_STAGES) + 1;                // heap index 2^s + block, one pad pair (rows on distinct 16-byte slots)
+HD int twl_slot(int row, int h) { return row * TWL_ROW + h; }
 template <int LOGM, int S0, int RHO, bool STRIDED, bool INVERSE, bool LAZY8 = false, int CC = -1, int T = NTT_THREADS, bool FW16 = false, bool TWL = false>
 HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, const u64 *twl = nullptr)
 {
@@ -261,7 +262,6 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
         const int P = STRIDED ? 1 : g.N_over_M + g.tile * g.C + lane;
         const int tb = (P << S0) + hi;
         constexpr bool IN_LDS = TWL && !STRIDED && S0 + RHO <= TWL_STAGES;
-        const u64 *tl = twl + 2 * (size_t)(lane * TWL_ROW);   // this row's heap
         u64 v[RAD];
 #pragma unroll
         for (int k = 0; k < RAD; k++) v[k] = lds[(x0 + (k << LO_BITS)) * g.pitch + lane];
@@ -272,7 +272,7 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
 #pragma unroll
                 for (int b = 0; b < (1 << u); b++) {
                     u64 w, ws;
-                    if (IN_LDS) { const U2 tw = ld2(tl + 2 * ((1 << (S0 + u)) + (hi << u) + b)); w = tw.a; ws = tw.b; }
+                    if (IN_LDS) { const U2 tw = ld2(twl + 2 * twl_slot(lane, (1 << (S0 + u)) + (hi << u) + b)); w = tw.a; ws = tw.b; }
                     else if (FW16) { const U2 tw = ld2g(W + 2 * (size_t)((tb << u) + b)); w = tw.a; ws = tw.b; }
                     else { w = W[(tb << u) + b]; ws = WS[(tb << u) + b]; }
 #pragma unroll
@@ -282,8 +282,8 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
                         if (LAZY8) {
                             if (u == 0 || (RHO == 4 && u == 2)) x = pm_fold(x, m);
                             const u64 y = shoup_lazy_t(v[k1], w, ws, nq);
-                            v[k0] = x + y;
-                            v[k1] = x + q4 - y;
+                            v[k0] = add_nw(x, y);
+                            v[k1] = sub_nn(add_nw(x, q4), y);
                         } else {
                             x = csub(x, nq2);
                             const u64 y = shoup_lazy_n(v[k1], w, ws, nq);
@@ -307,7 +307,7 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
                 const int half = 1 << (RHO - 1 - u);
 #pragma unroll
                 for (int b = 0; b < (1 << u); b++) {
-                    const U2 tw = IN_LDS ? ld2(tl + 2 * ((1 << (S0 + u)) + (hi << u) + b)) : ld2g(W + 2 * (size_t)((tb << u) + b));
+                    const U2 tw = IN_LDS ? ld2(twl + 2 * twl_slot(lane, (1 << (S0 + u)) + (hi << u) + b)) : ld2g(W + 2 * (size_t)((tb << u) + b));
                     const u64 w = tw.a, ws = tw.b;
 #pragma unroll
                     for (int j = 0; j < half; j++) {
@@ -316,8 +316,8 @@ HD void ntt_body_round(const NttArgs &a, int bx, int by, int tid, u64 *lds, cons
                         if (LAZY8) {
                             if (bnd[k0] + bnd[k1] > 16) { x = pm_fold(x, m); bnd[k0] = 2; }
                             if (bnd[k0] + bnd[k1] > 16) { y = pm_fold(y, m); bnd[k1] = 2; }
-                            v[k0] = x + y;
-                            v[k1] = shoup_lazy_t(x + q * (u64)bnd[k1] - y, w, ws, nq);  // + bnd q keeps the difference non-negative; below 16q
+                            v[k0] = add_nw(x, y);
+                            v[k1] = shoup_lazy_t(sub_nn(add_nw(x, q * (u64)bnd[k1]), y), w, ws, nq);  // + bnd q keeps the difference non-negative; below 16q
                             bnd[k0] = bnd[k0] + bnd[k1];
                             bnd[k1] = 4;
                         } else {
@@ -770,7 +770,7 @@ HD void ks_row_twiddle_fill(const NttArgs &a, int bx, int J, bool inverse, int t
         while ((2 << s) <= h) s++;
         const int P = g.N_over_M + g.tile * g.C + row;
         const U2 tw = ld2g(tab + 2 * (size_t)((P << s) + (h - (1 << s))));
-        st2(twl + 2 * (size_t)(row * TWL_ROW + h), tw);
+        st2(twl + 2 * (size_t)twl_slot(row, h), tw);
     }
 }
 // The row pass of a digit transform reads the strided pass's output as it is (no load op in a second pass): the tile of the NEXT
@@ -803,6 +803,17 @@ HD void ks_row_tile_commit(const NttArgs &fa, int bx, int by, int tid, const U2 
 // after the forward rounds of digit I: acc_k[pair] += T * key[I][k][J].  The kernel only runs on pseudo-Mersenne moduli (ModDev::pm_ok,
 // 16q <= 2^64): truncated Shoup products in [0,4q), sums folded below 2q by pm_fold after every third digit, so they never
 // exceed 2q + 3 * 4q = 14q < 2^64
+#ifndef KSROW_DEPTH
+#define KSROW_DEPTH 1   // measured (config 2, /s, row kernel us): depth 1 320 / 428, depth 2 (9 spilled registers) 310 / 451, loads fenced by the stores 318 / 438
+#endif
+struct KsIdx { int gi, l0, l1; };
+template <int CM, int CC> HD KsIdx ks_row_idx(const NttArgs &fa, const NttGeom &g, int tid, int k)
+{
+    int xx, lane;
+    KsIdx r;   // recomputed where needed (a few integer operations) rather than kept in 3 x NP registers
+    ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, r.gi, r.l0, r.l1);
+    return r;
+}
 template <int CM, int CC>
 HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, int J, int I, int tid, const u64 *lds, u64 *acc0, u64 *acc1)
 {
@@ -814,17 +825,27 @@ HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, i
     const gptr dptr = diag ? as_global(x.mul_ptrs[b]) + x.mul_shift + (size_t)J * g.n : as_global(nullptr);
     u64 *ap = diag ? x.acc + ((size_t)b * x.L + J) * g.n : nullptr;
     const bool fold = (I % 3) == 2 && I != x.L - 1;   // the flush phase folds after the last digit
+    // The key words of a pair are requested KSROW_DEPTH pairs ahead of their products, and the stores of the plain product come
+    // after every key load of the phase (a store fences the loads behind it for the compiler): the wave waits for about one
+    // round trip per phase instead of one per pair.
+    constexpr int DEPTH = KSROW_DEPTH < KSROW_NP ? KSROW_DEPTH : KSROW_NP;
+    U2 k0[KSROW_NP], k0s[KSROW_NP], k1[KSROW_NP], k1s[KSROW_NP];
+    auto request = [&](int k) {
+        const int gi = ks_row_idx<CM, CC>(fa, g, tid, k).gi;
+        k0[k] = ld2(x.key + kofs + gi); k0s[k] = ld2(x.key_s + kofs + gi);
+        k1[k] = ld2(x.key + kofs + kstep + gi); k1s[k] = ld2(x.key_s + kofs + kstep + gi);
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) request(k);
 #pragma unroll
     for (int k = 0; k < KSROW_NP; k++) {
-        int xx, lane, gi, l0, l1;
-        ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
-        const U2 k0 = ld2(x.key + kofs + gi), k0s = ld2(x.key_s + kofs + gi);
-        const U2 k1 = ld2(x.key + kofs + kstep + gi), k1s = ld2(x.key_s + kofs + kstep + gi);
-        const u64 v0 = lds[l0], v1 = lds[l1];
-        acc0[2 * k] += shoup_lazy_t(v0, k0.a, k0s.a, nq);
-        acc0[2 * k + 1] += shoup_lazy_t(v1, k0.b, k0s.b, nq);
-        acc1[2 * k] += shoup_lazy_t(v0, k1.a, k1s.a, nq);
-        acc1[2 * k + 1] += shoup_lazy_t(v1, k1.b, k1s.b, nq);
+        const KsIdx ix = ks_row_idx<CM, CC>(fa, g, tid, k);
+        const u64 v0 = lds[ix.l0], v1 = lds[ix.l1];
+        acc0[2 * k] = add_nw(acc0[2 * k], shoup_lazy_t(v0, k0[k].a, k0s[k].a, nq));
+        acc0[2 * k + 1] = add_nw(acc0[2 * k + 1], shoup_lazy_t(v1, k0[k].b, k0s[k].b, nq));
+        acc1[2 * k] = add_nw(acc1[2 * k], shoup_lazy_t(v0, k1[k].a, k1s[k].a, nq));
+        acc1[2 * k + 1] = add_nw(acc1[2 * k + 1], shoup_lazy_t(v1, k1[k].b, k1s[k].b, nq));
+        if (k + DEPTH < KSROW_NP) request(k + DEPTH);
         if (fold) {
 #pragma unroll
             for (int e = 0; e < 2; e++) {
@@ -832,18 +853,29 @@ HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, i
                 acc1[2 * k + e] = pm_fold(acc1[2 * k + e], m);
             }
         }
-        if (diag) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product (lazy input)
-            const U2 d = ld2g(dptr + gi);
-            U2 ac = ld2(ap + gi);
+    }
+    if (diag) {  // the diagonal digit is NTT_J(galois(c1)): reuse it for the plain product (lazy input); one pair requested ahead
+        U2 d[KSROW_NP], ds[KSROW_NP], ac[KSROW_NP];
+        auto drequest = [&](int k) {
+            const int gi = ks_row_idx<CM, CC>(fa, g, tid, k).gi;
+            d[k] = ld2g(dptr + gi);
+            ac[k] = ld2(ap + gi);
+            ds[k] = x.mul_s_off ? ld2g(dptr + x.mul_s_off + gi) : U2{0, 0};
+        };
+        drequest(0);
+#pragma unroll
+        for (int k = 0; k < KSROW_NP; k++) {
+            const KsIdx ix = ks_row_idx<CM, CC>(fa, g, tid, k);
+            const u64 v0 = lds[ix.l0], v1 = lds[ix.l1];
             if (x.mul_s_off) {  // Shoup product with the table's quotients: canonical sum + [0,4q) -> fold below 2q -> canonical
-                const U2 ds = ld2g(dptr + x.mul_s_off + gi);
-                ac.a = csub(pm_fold(ac.a + shoup_lazy_t(v0, d.a, ds.a, nq), m), nq);
-                ac.b = csub(pm_fold(ac.b + shoup_lazy_t(v1, d.b, ds.b, nq), m), nq);
+                ac[k].a = csub(pm_fold(add_nw(ac[k].a, shoup_lazy_t(v0, d[k].a, ds[k].a, nq)), m), nq);
+                ac[k].b = csub(pm_fold(add_nw(ac[k].b, shoup_lazy_t(v1, d[k].b, ds[k].b, nq)), m), nq);
             } else {
-                ac.a = addmod(ac.a, mulmod(v0, d.a, m), m.q);
-                ac.b = addmod(ac.b, mulmod(v1, d.b, m), m.q);
+                ac[k].a = addmod(ac[k].a, mulmod(v0, d[k].a, m), m.q);
+                ac[k].b = addmod(ac[k].b, mulmod(v1, d[k].b, m), m.q);
             }
-            st2(ap + gi, ac);
+            st2(ap + ix.gi, ac[k]);
+            if (k + 1 < KSROW_NP) drequest(k + 1);
         }
     }
 }
@@ -855,13 +887,16 @@ HD void ks_row_flush_phase(const NttArgs &fa, int bx, int J, int tid, u64 *lds, 
     const ModDev m = mod_at_u(fa.mods, J);
 #pragma unroll
     for (int k = 0; k < KSROW_NP; k++) {
-        int xx, lane, gi, l0, l1;
-        ntt_pair<false>(fa, g, tid + k * KSROW_THREADS, xx, lane, gi, l0, l1);
+        const KsIdx ix = ks_row_idx<CM, CC>(fa, g, tid, k);
         u64 v0 = pm_fold(acc[2 * k], m), v1 = pm_fold(acc[2 * k + 1], m);
         if (canon_out) {
             v0 = csub(v0, m.nq); v1 = csub(v1, m.nq);
-            st2(canon_out + gi, U2{v0, v1});
-        } else { lds[l0] = v0; lds[l1] = v1; }
+#ifdef KSROW_S0_STREAM
+            st2_stream(canon_out + ix.gi, U2{v0, v1});
+#else
+            st2(canon_out + ix.gi, U2{v0, v1});   // plain: a non-temporal store here took ~2.4x as long to complete (17,000 vs 7,000 cycles under load)
+#endif
+        } else { lds[ix.l0] = v0; lds[ix.l1] = v1; }
     }
 }
 // inverse row pass output (first inverse pass: plain stream store of the tile)

@@ -70,6 +70,19 @@ int rt_stream_wait_event(rt_stream s, void *ev) { return rt_check(hipStreamWaitE
 #define NTT_BX(a) ((int)(blockIdx.x & ((1u << (a).tiles_log) - 1)))
 #define NTT_BY(a) ((int)(blockIdx.x >> (a).tiles_log))
 
+// Synchronisation between the phases of a tile.  A workgroup of ONE wave (the fused row kernel) needs no barrier: its LDS operations
+// execute in program order, so a wave-scope fence (ordering for the compiler, no instruction) is enough.  __syncthreads() would also
+// be correct but its workgroup-scope release is an s_waitcnt vmcnt(0): every phase boundary would wait for ALL of the wave's
+// outstanding global loads and stores (the tile and key words requested ahead, and stores whose completion takes thousands of
+// cycles under load) -- measured: the S_0 stores alone held the next phase for ~7,000 cycles per workgroup.
+template <int T> static __device__ __forceinline__ void tile_sync()
+{
+    if constexpr (T <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else __syncthreads();
+}
 // CC = tile columns as a compile-time constant (full tiles) or -1 (ragged tiles of small N: taken from the arguments);
 // T = lanes per workgroup (256: radix-16 rounds, 512: radix-8 rounds)
 template <int LOGM, bool STRIDED, bool INVERSE, int CC, int T, int SCH = T, bool TWL = false>
@@ -82,7 +95,7 @@ struct NttRounds {
         if constexpr (I < R) {
             constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
             ntt_body_round<LOGM, S0, RHO, STRIDED, false, LAZY8, CC, T, SCH == 512, TWL>(a, bx, by, threadIdx.x, lds, twl);
-            __syncthreads();
+            tile_sync<T>();
             fwd<I + 1, S0 + RHO, LAZY8>(a, bx, by, lds, twl);
         }
     }
@@ -92,7 +105,7 @@ struct NttRounds {
         if constexpr (I >= 0) {
             constexpr int RHO = NttSched<LOGM, SCH>::rho(I);
             ntt_body_round<LOGM, SEND - RHO, RHO, STRIDED, true, LAZY8, CC, T, false, TWL>(a, bx, by, threadIdx.x, lds, twl);
-            __syncthreads();
+            tile_sync<T>();
             inv<I - 1, SEND - RHO, LAZY8>(a, bx, by, lds, twl);
         }
     }
@@ -121,7 +134,7 @@ static __device__ __forceinline__ void ntt_pass_tile(const NttArgs &a, int bx, i
     constexpr int CM = FULL ? LOGM : -1, CC = FULL ? TL - LOGM : -1;
     if constexpr (TWL) ks_row_twiddle_fill<CM, CC>(a, bx, by, INVERSE, threadIdx.x, twl);
     ntt_body_load<STRIDED, INVERSE, CM, CC, T>(a, bx, by, threadIdx.x, lds);
-    __syncthreads();
+    tile_sync<T>();
     ntt_tile_rounds<LOGM, STRIDED, INVERSE, CC, T, SCH, TWL, PM>(a, bx, by, lds, twl);
     ntt_body_store<STRIDED, INVERSE, CM, CC, T>(a, bx, by, threadIdx.x, lds);
 }
@@ -261,7 +274,11 @@ void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s)
 #ifdef HHE_STAMPS
 constexpr int STAMP_SLOTS = 24, STAMP_WGS = 4096;
 __device__ u64 g_ks_stamps[STAMP_WGS * STAMP_SLOTS];
-#define KS_STAMP(i) do { if (stamp_on) { const u64 t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) ((volatile u64 *)g_ks_stamps)[stamp_wg * STAMP_SLOTS + (i)] = t_; } } while (0)
+// the clock values stay in scalar registers until the workgroup is done (a store per stamp would make the wave wait for all its
+// outstanding vector memory operations at every phase boundary and distort the timeline it is meant to show)
+#define KS_STAMP(i) do { if (st_rec) stamps_[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KS_STAMP_I(base, I) do { const u64 t_ = __builtin_amdgcn_s_memtime(); if (!st_rec) { } else if ((I) == 0) stamps_[(base)] = t_; else if ((I) == 1) stamps_[(base) + 3] = t_; else if ((I) == 2) stamps_[(base) + 6] = t_; } while (0)
+#define KS_STAMP_FLUSH() do { if (stamp_on && threadIdx.x == 0) { _Pragma("unroll") for (int i_ = 0; i_ < 17; i_++) g_ks_stamps[stamp_wg * STAMP_SLOTS + i_] = stamps_[i_]; } } while (0)
 extern "C" int hhe_debug_read_stamps(u64 *out, size_t words)
 {
     if (words > (size_t)STAMP_WGS * STAMP_SLOTS) words = (size_t)STAMP_WGS * STAMP_SLOTS;
@@ -269,10 +286,13 @@ extern "C" int hhe_debug_read_stamps(u64 *out, size_t words)
 }
 #else
 #define KS_STAMP(i) do { } while (0)
+#define KS_STAMP_I(base, I) do { } while (0)
+#define KS_STAMP_FLUSH() do { } while (0)
 #endif
 #ifndef KSROW_WAVES
 #define KSROW_WAVES 4
 #endif
+
 template <int LOGM>
 __global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_row_kernel(NttArgs a, KsRowArgs x, NttArgs c0)
 {
@@ -290,72 +310,84 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_row_kernel(NttA
 #ifdef HHE_STAMPS
     const bool stamp_on = (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < STAMP_WGS;
     const unsigned stamp_wg = blockIdx.x >> 6;
+    u64 stamps_[17];
+#pragma unroll
+    for (int i_ = 0; i_ < 17; i_++) stamps_[i_] = 0;
 #endif
     if (blockIdx.x >= nmain) {
         const unsigned cb = blockIdx.x - nmain;
+#ifdef HHE_STAMPS
+        const bool st_rec = true;
+#endif
         KS_STAMP(0);
         ntt_pass_tile<LOGM, false, false, true, T, SCH, KSROW_TILE_LOG, TWL, true>(c0, (int)(cb & ((1u << a.tiles_log) - 1)), (int)(cb >> a.tiles_log), lds, twl);
         KS_STAMP(16);
-        KS_STAMP(23);
+        KS_STAMP_FLUSH();
         return;
     }
     const unsigned bid = blockIdx.x;
-    KS_STAMP(0);
     const int bx = (int)(bid & ((1u << a.tiles_log) - 1)), y = (int)(bid >> a.tiles_log);
     const int b = y / x.K, J = y % x.K, tid = threadIdx.x;
     const size_t n = (size_t)1 << a.logn;
-    u64 acc0[2 * KSROW_NP], acc1[2 * KSROW_NP];
+    {
+#ifdef HHE_STAMPS
+        const bool st_rec = true;
+#endif
+        KS_STAMP(0);
+        u64 acc0[2 * KSROW_NP], acc1[2 * KSROW_NP];
 #pragma unroll
-    for (int k = 0; k < 2 * KSROW_NP; k++) { acc0[k] = 0; acc1[k] = 0; }
-    U2 pf[KSROW_NP];  // the tile of the next digit, in flight
-    ks_row_tile_fetch<LOGM, CC>(a, bx, (b * x.L + 0) * x.K + J, tid, pf);   // beside the twiddle fill's own loads
-    if (TWL) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, false, tid, twl);
-    KS_STAMP(1);
-    for (int I = 0; I < x.L; I++) {
-        const int by = (b * x.L + I) * x.K + J;
-        ks_row_tile_commit<LOGM, CC>(a, bx, by, tid, pf, lds);
-        __syncthreads();
-        if (I + 1 < x.L) ks_row_tile_fetch<LOGM, CC>(a, bx, by + x.K, tid, pf);
-        KS_STAMP(2 + 3 * I);
-        ntt_tile_rounds<LOGM, false, false, CC, T, SCH, TWL, true>(a, bx, by, lds, twl);
-        KS_STAMP(3 + 3 * I);
-        if (TWL && I == x.L - 1) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, tid, twl);  // behind the key products; every wave is past the forward rounds
-        ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, tid, lds, acc0, acc1);
-        __syncthreads();
-        KS_STAMP(4 + 3 * I);
-    }
-    if (J < x.L) {
-        if (x.U0) {  // generic key switch: S_0[j] is inverse-transformed as well
-            ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
-            __syncthreads();
+        for (int k = 0; k < 2 * KSROW_NP; k++) { acc0[k] = 0; acc1[k] = 0; }
+        U2 pf[KSROW_NP];  // the tile of the next digit, in flight
+        ks_row_tile_fetch<LOGM, CC>(a, bx, (b * x.L + 0) * x.K + J, tid, pf);   // beside the twiddle fill's own loads
+        if (TWL) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, false, tid, twl);
+        KS_STAMP(1);
+        for (int I = 0; I < x.L; I++) {
+            const int by = (b * x.L + I) * x.K + J;
+            ks_row_tile_commit<LOGM, CC>(a, bx, by, tid, pf, lds);
+            tile_sync<T>();
+            if (I + 1 < x.L) ks_row_tile_fetch<LOGM, CC>(a, bx, by + x.K, tid, pf);
+            KS_STAMP_I(2, I);
+            ntt_tile_rounds<LOGM, false, false, CC, T, SCH, TWL, true>(a, bx, by, lds, twl);
+            KS_STAMP_I(3, I);
+            if (TWL && I == x.L - 1) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, tid, twl);  // behind the key products: the forward rounds are over
+            ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, tid, lds, acc0, acc1);
+            tile_sync<T>();
+            KS_STAMP_I(4, I);
+        }
+        if (J < x.L) {
+            if (x.U0) {  // generic key switch: S_0[j] is inverse-transformed as well
+                ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
+                tile_sync<T>();
+                ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
+                ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U0 + (size_t)b * x.u_stride + (size_t)J * n);
+                tile_sync<T>();
+            } else ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
+            KS_STAMP(13);
+            ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
+            tile_sync<T>();
+            KS_STAMP(14);
             ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
-            ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U0 + (size_t)b * x.u_stride + (size_t)J * n);
-            __syncthreads();
-        } else ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
-        KS_STAMP(13);
-        ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
-        __syncthreads();
-        KS_STAMP(14);
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
-        KS_STAMP(15);
-        ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U1 + (size_t)b * x.u_stride + (size_t)J * n);
-    } else {
-        ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
-        __syncthreads();
-        KS_STAMP(11);
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
-        KS_STAMP(12);
-        ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 0) * n);
-        __syncthreads();
-        KS_STAMP(13);
-        ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
-        __syncthreads();
-        KS_STAMP(14);
-        ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
-        KS_STAMP(15);
-        ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 1) * n);
+            KS_STAMP(15);
+            ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.U1 + (size_t)b * x.u_stride + (size_t)J * n);
+        } else {
+            ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
+            tile_sync<T>();
+            KS_STAMP(11);
+            ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
+            KS_STAMP(12);
+            ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 0) * n);
+            tile_sync<T>();
+            KS_STAMP(13);
+            ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
+            tile_sync<T>();
+            KS_STAMP(14);
+            ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
+            KS_STAMP(15);
+            ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, x.Usp + ((size_t)b * 2 + 1) * n);
+        }
+        KS_STAMP(16);
     }
-    KS_STAMP(16);
+    KS_STAMP_FLUSH();
 }
 int k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s)
 {

@@ -40,6 +40,17 @@ HD u64 pm_fold(u64 x, const ModDev &m)
     const u64 r = ((u64)(hi & m.pm_mask) << 32) | (u32)x;
     return (u64)(hi >> m.pm_sh) * m.pm_c + r;
 }
+// Range bookkeeping of the lazy paths, checked where it can be: the tests-only emulator is built with -DHHE_RANGE_CHECK and
+// aborts when a lazy sum wraps 64 bits or a lazy difference goes negative (the adversarial-residue tests drive the bounds);
+// in the product these are a plain add / subtract.
+#if defined(HHE_RANGE_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+void hhe_range_violation(const char *what);
+inline u64 add_nw(u64 a, u64 b) { const u64 s = a + b; if (s < a) hhe_range_violation("lazy sum wrapped 2^64"); return s; }
+inline u64 sub_nn(u64 a, u64 b) { if (a < b) hhe_range_violation("lazy difference went negative"); return a - b; }
+#else
+HD u64 add_nw(u64 a, u64 b) { return a + b; }
+HD u64 sub_nn(u64 a, u64 b) { return a - b; }
+#endif
 // x >= c ? x - c : x given nc = 2^64 - c, for c <= 2^63 and x < 2c: one 64-bit add and a select on the sign of the sum
 HD u64 csub(u64 x, u64 nc)
 {

@@ -32,6 +32,15 @@ int main(int argc, char **argv)
     pasta::SecretKey he_sk{read_words(f, (size_t)K * n)};
     auto sym_key = read_words(f, 256);
     auto plain_record = read_words(f, hdr[4]);
+    // second key objects of the same secret key (the CSP's own: csp_he_gk for flatten, csp rk for the FC; Analyst.cpp:70-94) + a weight row
+    auto hdr2 = read_words(f, 1);
+    pasta::GaloisKeys csp_gk;
+    for (uint64_t i = 0; i < hdr2[0]; i++) {
+        uint32_t elt = (uint32_t)read_words(f, 1)[0];
+        csp_gk.keys[elt] = read_words(f, ksk);
+    }
+    pasta::RelinKeys csp_rk{read_words(f, ksk)};
+    pasta::Ciphertext w_row{read_words(f, ctw), 2};
     fclose(f);
     try {
         auto ctx = std::make_shared<pasta::HheContext>(logn, q, hdr[2], 0);
@@ -67,6 +76,24 @@ int main(int argc, char **argv)
             auto dec = sealhelper::decrypting(flat, he_sk, *ctx, 256);
             fwrite(dec.data(), 8, dec.size(), o);
         }
+        // the CSP's request loop: a FRESH cipher object per request built from the same key objects by value (CSP.cpp:238-242), flatten
+        // with the GaloisKeys the call names (CSP.cpp:271-278), then the per-record loop as one batched call and one FC row
+        pasta::Ciphertext f2;
+        for (int req = 0; req < 3; req++) {
+            pasta::PASTA_SEAL per_request(ctx, pasta::PublicKey{}, pasta::SecretKey{}, rk, gk);
+            std::vector<pasta::Ciphertext> b2 = per_request.decomposition(record, {enc_key}, true);
+            per_request.flatten(b2, f2, csp_gk);
+        }
+        fwrite(f2.words.data(), 8, f2.words.size(), o);
+        std::vector<std::vector<uint64_t>> recs = {record, record};
+        std::vector<pasta::Ciphertext> batch = HHE.decompose(recs, {enc_key}, csp_gk, true);
+        fwrite(batch[0].words.data(), 8, batch[0].words.size(), o);
+        fwrite(batch[1].words.data(), 8, batch[1].words.size(), o);
+        pasta::Ciphertext fc;
+        sealhelper::fc_row(*ctx, batch[0], w_row, csp_rk, csp_gk, 3, fc);
+        fwrite(fc.words.data(), 8, fc.words.size(), o);
+        printf("key objects uploaded: %llu, resident sets: %zu, encrypted-key uploads: %llu\n", (unsigned long long)ctx->keys().uploads(),
+               ctx->keys().resident(), (unsigned long long)ctx->key_uploads);
         fclose(o);
         try { pasta::PASTA bad(ctx, std::vector<uint64_t>(255, 1), hdr[2]); printf("NO THROW\n"); return 3; }
         catch (const std::runtime_error &e) { printf("throws: %s\n", e.what()); }

@@ -24,6 +24,9 @@ void csp_decompose(shared_ptr<SEALContext> context, PublicKey analyst_pk, Secret
         HHE.flatten(record, tmp, csp_gk);
         processed.push_back(tmp);
     }
+    // the same loop as one batched device call (an addition of the adapter, not a reference signature)
+    vector<Ciphertext> batched = HHE.decompose(enc_data, user_enc_sym_key, csp_gk, true);
+    processed.insert(processed.end(), batched.begin(), batched.end());
 }
 
 // CSP.cpp:288-323

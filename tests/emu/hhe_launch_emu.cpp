@@ -11,6 +11,13 @@
 #include "hhe_kernel_bodies.h"
 #include "hhe_launch.h"
 
+// -DHHE_RANGE_CHECK (this build only): a lazy value left its 64-bit range -- a bug in the range analysis, never a data error
+void hhe_range_violation(const char *what)
+{
+    fprintf(stderr, "emu: range violation: %s\n", what);
+    abort();
+}
+
 const char *rt_backend_name() { return "cpu-emulator(tests-only)"; }
 const char *rt_last_error() { return "emu"; }
 int rt_set_device(int) { return 0; }
@@ -120,6 +127,7 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
         u64 *const twl = TWL ? lds.data() + KSROW_LDS : nullptr;
         std::vector<u64> acc0((size_t)T * 2 * KSROW_NP), acc1((size_t)T * 2 * KSROW_NP);
         std::vector<U2> pf((size_t)T * KSROW_NP);
+        auto PF = [&](int t) { return &pf[(size_t)t * KSROW_NP]; };
         auto A0 = [&](int t) { return &acc0[(size_t)t * 2 * KSROW_NP]; };
         auto A1 = [&](int t) { return &acc1[(size_t)t * 2 * KSROW_NP]; };
 #pragma omp for collapse(2)
@@ -134,30 +142,32 @@ static void ks_row_emu(const NttArgs &a, const KsRowArgs &x, const NttArgs &c0, 
         for (int y = 0; y < gy; y++)
             for (int bx = 0; bx < gx; bx++) {
                 const int b = y / x.K, J = y % x.K;
-                std::fill(acc0.begin(), acc0.end(), 0);
-                std::fill(acc1.begin(), acc1.end(), 0);
-                for (int t = 0; t < T; t++) ks_row_tile_fetch<LOGM, CC>(a, bx, (b * x.L + 0) * x.K + J, t, &pf[(size_t)t * KSROW_NP]);
-                if (TWL) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, false, t, twl);
-                for (int I = 0; I < x.L; I++) {
-                    const int by = (b * x.L + I) * x.K + J;
-                    for (int t = 0; t < T; t++) ks_row_tile_commit<LOGM, CC>(a, bx, by, t, &pf[(size_t)t * KSROW_NP], lds.data());
-                    if (I + 1 < x.L) for (int t = 0; t < T; t++) ks_row_tile_fetch<LOGM, CC>(a, bx, by + x.K, t, &pf[(size_t)t * KSROW_NP]);
-                    tile_rounds_emu<LOGM, false, false, CC, T, SCH, TWL>(a, bx, by, lds.data(), twl);
-                    if (TWL && I == x.L - 1) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, t, twl);
-                    for (int t = 0; t < T; t++) ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, t, lds.data(), A0(t), A1(t));
-                }
-                auto inverse_to = [&](std::vector<u64> &acc, u64 *out) {
-                    for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), &acc[(size_t)t * 2 * KSROW_NP], nullptr);
-                    tile_rounds_emu<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds.data(), twl);
-                    for (int t = 0; t < T; t++) ks_row_store_phase<LOGM, CC>(a, bx, J, t, lds.data(), out);
-                };
-                if (J < x.L) {
-                    if (x.U0) inverse_to(acc0, x.U0 + (size_t)b * x.u_stride + (size_t)J * n);
-                    else for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), A0(t), x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
-                    inverse_to(acc1, x.U1 + (size_t)b * x.u_stride + (size_t)J * n);
-                } else {
-                    inverse_to(acc0, x.Usp + ((size_t)b * 2 + 0) * n);
-                    inverse_to(acc1, x.Usp + ((size_t)b * 2 + 1) * n);
+                {
+                    if (TWL) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, false, t, twl);
+                    std::fill(acc0.begin(), acc0.end(), 0);
+                    std::fill(acc1.begin(), acc1.end(), 0);
+                    for (int t = 0; t < T; t++) ks_row_tile_fetch<LOGM, CC>(a, bx, (b * x.L + 0) * x.K + J, t, PF(t));
+                    for (int I = 0; I < x.L; I++) {
+                        const int by = (b * x.L + I) * x.K + J;
+                        for (int t = 0; t < T; t++) ks_row_tile_commit<LOGM, CC>(a, bx, by, t, PF(t), lds.data());
+                        if (I + 1 < x.L) for (int t = 0; t < T; t++) ks_row_tile_fetch<LOGM, CC>(a, bx, by + x.K, t, PF(t));
+                        tile_rounds_emu<LOGM, false, false, CC, T, SCH, TWL>(a, bx, by, lds.data(), twl);
+                        if (TWL && I == x.L - 1) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, t, twl);
+                        for (int t = 0; t < T; t++) ks_row_mac_phase<LOGM, CC>(x, a, bx, b, J, I, t, lds.data(), A0(t), A1(t));
+                    }
+                    auto inverse_to = [&](std::vector<u64> &acc, u64 *out) {
+                        for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), &acc[(size_t)t * 2 * KSROW_NP], nullptr);
+                        tile_rounds_emu<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds.data(), twl);
+                        for (int t = 0; t < T; t++) ks_row_store_phase<LOGM, CC>(a, bx, J, t, lds.data(), out);
+                    };
+                    if (J < x.L) {
+                        if (x.U0) inverse_to(acc0, x.U0 + (size_t)b * x.u_stride + (size_t)J * n);
+                        else for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), A0(t), x.S + (((size_t)b * 2 + 0) * x.K + J) * n);
+                        inverse_to(acc1, x.U1 + (size_t)b * x.u_stride + (size_t)J * n);
+                    } else {
+                        inverse_to(acc0, x.Usp + ((size_t)b * 2 + 0) * n);
+                        inverse_to(acc1, x.Usp + ((size_t)b * 2 + 1) * n);
+                    }
                 }
             }
     }

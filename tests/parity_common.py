@@ -363,3 +363,31 @@ def check_key_sets(X, S, orc, mem, threads=True):
     assert (res["A"][0] == O.rotate_rows(cts[0], -128, gkA)[0]).all() and (res["B"][0] == O.rotate_rows(cts[0], -128, gkB)[0]).all()
     for ks in (A, Bs, R2):
         ks.close()
+
+
+def check_matmul_adversarial(X, S, orc, mem, pattern):
+    """The matmul loop on worst-case residues (the lazy ranges are tightest at 60-bit primes, 16q ~ 2^64): the 'ciphertext' the
+    loop starts from, the symmetric words and -- for 'max_keys' -- every key-switch key word sit at q_j - 1 (or alternate with
+    0).  Nothing here is a valid encryption; the oracle's exact arithmetic defines the expected words all the same."""
+    O = S.O
+    enc = np.zeros(O.ct_shape, np.uint64)
+    for j in range(O.L):
+        if pattern == "alt":
+            enc[:, j, ::2] = S.q[j] - 1
+        else:
+            enc[:, j, :] = S.q[j] - 1
+    rk, gk = S.rk, S.gk
+    if pattern == "max_keys":
+        rk = np.zeros_like(S.rk)
+        for j in range(O.K):
+            rk[:, :, j, :] = S.q[j] - 1
+        gk = orc.GaloisKeys(S.gk.elts, np.stack([rk] * len(S.gk.elts)))
+    ks = X.keyset()
+    ks.set_relin(rk)
+    for e, k in zip(gk.elts, gk.keys):
+        ks.set_galois(int(e), k)
+    cw = np.full((1, 128), S.t - 1, np.uint64)
+    out = mem.empty((1,) + O.ct_shape)
+    X.transcipher(mem.to_dev(enc), cw, [128], [0], out, rk=ks, gk=ks)
+    assert (mem.to_host(out)[0] == O.transcipher_block(enc, rk, gk, cw[0], 0)).all(), pattern
+    ks.close()

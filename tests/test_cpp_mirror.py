@@ -15,6 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(orc, tmp_path, libdir, libname, extra_env=None):
     S = Setup(orc, 10, [50] * 9, extra_steps=(-128, -256))
     O = S.O
+    # the CSP's own key objects under the same secret key, different randomness (Analyst.cpp:70-94); -2 serves the 3-input FC row
+    csp_gk = O.keygen_galois(S.sk, [int(O.galois_elt(s)) for s in (0, -1, 128, -128, -256, -2)], 808)
+    csp_rk = O.keygen_relin(S.sk, 909)
+    w_vals = np.array([3, 5, 7], dtype=np.uint64)
+    w_row = O.encrypt(S.pk, O.encode(w_vals), 77)
     pt = np.array([(7 * i + 3) % 256 for i in range(300)], dtype=np.uint64)
     record = orc.pasta_encrypt(S.t, S.key, pt)
     blob = tmp_path / "in.bin"
@@ -30,6 +35,12 @@ def _run(orc, tmp_path, libdir, libname, extra_env=None):
         np.ascontiguousarray(S.sk, dtype=np.uint64).tofile(f)
         S.key.tofile(f)
         np.asarray(pt, dtype=np.uint64).tofile(f)
+        np.array([len(csp_gk.elts)], dtype=np.uint64).tofile(f)
+        for e, k in zip(csp_gk.elts, csp_gk.keys):
+            np.array([int(e)], dtype=np.uint64).tofile(f)
+            k.tofile(f)
+        csp_rk.tofile(f)
+        w_row.tofile(f)
     exe = tmp_path / "mirror"
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "mirror_main.cpp"), "-L" + libdir, "-l" + libname,
@@ -51,7 +62,9 @@ def _run(orc, tmp_path, libdir, libname, extra_env=None):
     o2 = base + ctw + ctw // 2 * 3
     ssum = words[o2:o2 + ctw].reshape(O.ct_shape)
     sym_ct, sym_back = words[o2 + ctw:o2 + ctw + len(pt)], words[o2 + ctw + len(pt):o2 + ctw + 2 * len(pt)]
-    dec_i64 = words[o2 + ctw + 2 * len(pt):].view(np.int64)
+    o3 = o2 + ctw + 2 * len(pt)
+    dec_i64 = words[o3:o3 + 256].view(np.int64)
+    extra = words[o3 + 256:].reshape(4, *O.ct_shape)   # flatten with csp_gk, batched decompose x 2, FC row
     assert (sym_ct == record).all() and (sym_back == np.asarray(pt, dtype=np.uint64)).all()   # pasta::PASTA encrypt / decrypt
     assert "throws: Invalid Key length" in r.stdout
     assert len(dec_i64) == 256 and (dec_i64 == np.asarray(pt[:256], dtype=np.int64)).all()    # sealhelper::decrypting
@@ -67,6 +80,19 @@ def _run(orc, tmp_path, libdir, libname, extra_env=None):
     # mask-free flatten decrypts to the record (SEAL_Cipher.cpp:170-181 semantics): first 300 slots
     dec = O.decode(O.decrypt(S.sk, cts[nb]))
     assert (dec[:256] == pt[:256]).all()
+    # key objects named per call: flatten with the CSP's GaloisKeys differs from flatten with the cipher object's own, and both equal
+    # the oracle called with that object; the batched decompose masks the ragged block (44 words) before flattening
+    assert (extra[0] == O.flatten(np.stack(refs), csp_gk)).all() and not (extra[0] == flat).all()
+    masked = list(refs)
+    masked[2] = O.mask(refs[2], np.ones(44, np.uint64))
+    ref_dec = O.flatten(np.stack(masked), csp_gk)
+    assert (extra[1] == ref_dec).all() and (extra[2] == ref_dec).all()
+    ref_fc, _ = O.fc_row(ref_dec, w_row, csp_rk, csp_gk, 3)
+    assert (extra[3] == ref_fc).all()
+    assert int(O.decode(O.decrypt(S.sk, extra[3]))[2]) == int(np.dot(pt[:3], w_vals)) % S.t
+    # three requests built three cipher objects from the same key objects by value: 4 objects went to the device once (rk, gk, csp gk,
+    # csp rk), the encrypted PASTA key once
+    assert "key objects uploaded: 4, resident sets: 4, encrypted-key uploads: 1" in r.stdout, r.stdout
     return r.stdout
 
 

@@ -125,11 +125,10 @@ BFV_DEFAULT_16384 = [281474976546817, 281474976317441, 281474975662081, 56294995
                      562949952274433, 562949951979521, 562949951881217, 562949951619073]
 
 
-def test_config1_dry_run_mnist_sample_end_to_end(orc, api, lib, mem):
-    """BASELINE config 1 shape (reference defaults: t=65537, N=16384, BFVDefault 9 primes): one 784-word 2-bit
-    sample -> 7 transcipherings -> mask (last block) -> flatten -> one FC row (multiply + relinearize +
-    encrypted_vec_sum over all default Galois keys), checked the way the reference checks itself
-    (hhe_pktnn_examples.cpp:639-648, 692-699): decrypt == input, FC == plain integer matmul."""
+@pytest.fixture(scope="module")
+def cfg1(orc):
+    """the reference's default parameters (t=65537, N=16384, BFVDefault 9 primes; configs/config.cpp:19-20) with every key the
+    MNIST flow needs: all default Galois elements (Analyst.cpp:62-65) plus the PASTA / flatten steps"""
     S = Setup.__new__(Setup)
     S.t, S.logn, S.n, S.q = T, 14, 1 << 14, BFV_DEFAULT_16384
     S.O = O = orc.Oracle(14, S.q, T)
@@ -141,6 +140,15 @@ def test_config1_dry_run_mnist_sample_end_to_end(orc, api, lib, mem):
     S.gk = O.keygen_galois(S.sk, elts, 7)
     S.key = np.array([(i * 2654435761 + 12345) % T for i in range(256)], dtype=np.uint64)
     S.enc_key = O.encrypt(S.pk, O.pasta_pack_key(S.key), 11)
+    return S
+
+
+def test_config1_dry_run_mnist_sample_end_to_end(orc, api, lib, mem, cfg1):
+    """BASELINE config 1 shape (reference defaults: t=65537, N=16384, BFVDefault 9 primes): one 784-word 2-bit
+    sample -> 7 transcipherings -> mask (last block) -> flatten -> one FC row (multiply + relinearize +
+    encrypted_vec_sum over all default Galois keys), checked the way the reference checks itself
+    (hhe_pktnn_examples.cpp:639-648, 692-699): decrypt == input, FC == plain integer matmul."""
+    S, O = cfg1, cfg1.O
     X = api.Context(S.logn, S.q, S.t, lib=lib)
     S.load_keys(X)
     import json
@@ -419,3 +427,83 @@ def test_seal_streams_in_transcipher_stream_out(orc, api, lib, mem, small):
         rpid, rsize, rn, rcms, words = sw.parse_ciphertext(stream[b * half:(b + 1) * half])
         assert (rpid, rsize, rn, rcms) == (pid_d, 2, small.n, X.L)
         assert (words.reshape(small.O.ct_shape) == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw[b, :ncw[b]], b)).all()
+
+
+def test_config3_mnist_64_images_whole_protocol(orc, api, lib, mem, cfg1):
+    """BASELINE config 3 at fixture scale: the first 64 MNIST test images (tests/golden/mnist_64.json, 2-bit pixels) through the
+    device protocol in ONE batch -- client PASTA encryption, CSP decompose (448 transcipherings + mask + flatten), the 784 x 10
+    FC (640 rows in one call, the CSP's own RelinKeys object for the relinearization and the analyst's default GaloisKeys object
+    for the slot sums, as CSP.cpp:306, 312-316 names them), analyst decryption.  The reference's acceptance test
+    (hhe_pktnn_examples.cpp:692-699, 861-862): HHE logits == plain integer matmul for every image, prediction == label
+    wherever the plain model is right."""
+    import json
+    import os
+    S, O = cfg1, cfg1.O
+    here = os.path.dirname(os.path.abspath(__file__))
+    fx = json.load(open(os.path.join(here, "golden", "mnist_64.json")))
+    W = np.array(json.load(open(os.path.join(here, "golden", "mnist_1fc.json")))["weights_rows"], dtype=np.int64)
+    packed = np.array([list(bytes.fromhex(h)) for h in fx["pixels_2bit_hex"]], dtype=np.uint8)
+    pix = ((packed[:, :, None] >> (2 * np.arange(4))) & 3).reshape(len(packed), 784).astype(np.int64)
+    NS, n_in = pix.shape
+    assert NS == 64 and (pix @ W.T == np.array(fx["plain_logits"])).all()
+    X = api.Context(S.logn, S.q, S.t, lib=lib)
+    pasta, analyst_gk, csp_gk, csp_rk = X.keyset(), X.keyset(), X.keyset(), X.keyset()
+    pasta.set_relin(S.rk)
+    dflt = {int(e) for e in O.galois_elts_all()}
+    for e, k in zip(S.gk.elts, S.gk.keys):
+        e = int(e)
+        if e in dflt:
+            analyst_gk.set_galois(e, k)
+        pasta.set_galois(e, k)
+    # csp_gk = add_gk_indices + the flatten steps -128 i of a 7-block record (hhe_pktnn_examples.cpp:601-615), its own randomness
+    gk_flat = O.keygen_galois(S.sk, [int(O.galois_elt(s)) for s in [0, -1, 128] + [-128 * i for i in range(1, 7)]], 71)
+    for e, k in zip(gk_flat.elts, gk_flat.keys):
+        csp_gk.set_galois(int(e), k)
+    rk_csp = O.keygen_relin(S.sk, 72)
+    csp_rk.set_relin(rk_csp)
+    d_sym = mem.empty((NS, n_in))
+    X.plain_crypt(S.key, mem.to_dev(pix.astype(np.uint64)), NS, n_in, d_sym)
+    recs = mem.to_host(d_sym)
+    assert (recs[5] == orc.pasta_encrypt(T, S.key, pix[5])).all()
+    flat = mem.empty((NS,) + O.ct_shape)
+    X.decompose(mem.to_dev(S.enc_key), recs, flat, mask_last=True, rk=pasta, gk=pasta, flatten_gk=csp_gk)
+    # one record against the oracle's op sequence with the same three key objects
+    cw, ncw = S.sym_blocks(orc, pix[63])
+    blocks = [O.transcipher_block(S.enc_key, S.rk, S.gk, cw[b, :ncw[b]], b) for b in range(7)]
+    blocks[6] = O.mask(blocks[6], np.ones(16, np.uint64))
+    assert (mem.to_host(flat)[63] == O.flatten(np.stack(blocks), gk_flat)).all()
+    wcs = np.stack([O.encrypt(S.pk, O.encode(W[r] % T), 40 + r) for r in range(10)])
+    import torch
+    vi = flat.repeat_interleave(10, dim=0).contiguous()   # item = (sample, neuron), neuron = item % 10
+    out = mem.empty((NS * 10,) + O.ct_shape)
+    X.fc_row(vi, mem.to_dev(wcs), 10, n_in, out, NS * 10, rk=csp_rk, gk=analyst_gk)
+    vals = mem.empty((NS * 10, O.n))
+    X.decrypt(S.sk, out, NS * 10, vals)
+    got = mem.to_host(vals)[:, n_in - 1].astype(np.int64).reshape(NS, 10)
+    logits = np.where(got > (T + 1) // 2, got - T, got)
+    plain = np.array(fx["plain_logits"])
+    assert ((logits - plain) % T == 0).all()
+    pred = logits.argmax(axis=1)
+    right = np.array(fx["argmax"]) == np.array(fx["labels"])
+    assert right.sum() == 58 and (pred[right] == np.array(fx["labels"])[right]).all() and (pred == np.array(fx["argmax"])).all()
+    del torch
+
+
+def test_key_sets_have_identity(orc, api, lib, mem):
+    """two GaloisKeys objects and two RelinKeys objects under one secret key on the device (CSP.cpp:238-242, 271-278, 306, 312-316):
+    N = 4096 runs rotations / relinearize through the fused row kernel and its per-key Shoup tables, N = 2048 the separate kernels"""
+    for logn, bits in ((12, [55] * 4), (11, [50] * 4)):
+        S = Setup(orc, logn, bits)
+        X = api.Context(S.logn, S.q, S.t, lib=lib)   # default set empty
+        pc.check_key_sets(X, S, orc, mem)
+        X.close()
+
+
+@pytest.mark.parametrize("pattern", ["max", "alt", "max_keys"])
+def test_matmul_loop_adversarial_residues(orc, api, lib, mem, pattern):
+    """worst-case residues through the fused matmul loop at 60-bit primes: N = 4096 (L = 2) and the metric's N = 2^15 (L = 3)"""
+    for logn in (12, 15):
+        S = Setup(orc, logn, [60] * (3 if logn == 12 else 4))
+        X = api.Context(S.logn, S.q, S.t, lib=lib)
+        pc.check_matmul_adversarial(X, S, orc, mem, pattern)
+        X.close()

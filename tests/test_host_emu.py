@@ -399,3 +399,13 @@ def test_fc_row_variants_full_tiles(orc, api, emu_lib, mem, monkeypatch):
     Galois-gathered base) and the leaf sums (STORE_RACC with q_sp * galois(c0)) on the tile geometry the GPU runs"""
     S = Setup(orc, 12, [50] * 3, all_galois=True)
     pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=emu_lib), S, orc, mem, monkeypatch, n_in=21)
+
+
+@pytest.mark.parametrize("pattern", ["max", "alt", "max_keys"])
+def test_matmul_loop_adversarial_residues(orc, api, emu_lib, mem, pattern):
+    """worst-case residues through the fused matmul loop at 60-bit primes (N = 4096: the row kernel, its truncated Shoup
+    products and pseudo-Mersenne folds); the emulator is built with -DHHE_RANGE_CHECK, so a lazy sum that wraps 64 bits or a
+    lazy difference that goes negative aborts instead of hiding behind a congruent result"""
+    S = Setup(orc, 12, [60, 60, 60])
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    pc.check_matmul_adversarial(X, S, orc, mem, pattern)

@@ -164,3 +164,67 @@ def test_malformed_and_foreign_objects_are_rejected(api, emu_lib, mem, S, orc):
 
 def pc_ptr(a):
     return C.c_void_p(a.ctypes.data)
+
+
+@pytest.mark.parametrize("compr", [ZLIB, ZSTD])
+def test_compression_bombs_are_refused_before_they_are_inflated(api, emu_lib, mem, S, compr):
+    """the blobs arrive over gRPC: a few KB of zlib / zstd must not inflate into gigabytes -- the decoder stops at the largest
+    legitimate object of the context and reports an error (never a std::bad_alloc across the C boundary)"""
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    out = mem.empty(S.O.ct_shape)
+    bomb = obj(b"\x00" * (64 << 20), compr)          # 64 MiB of zeros: a few dozen KB compressed
+    assert len(bomb) < (1 << 20)
+    with pytest.raises(RuntimeError, match="inflates beyond the largest object"):
+        X.seal_load_ciphertext(bomb, out)
+    # key objects are bounded as well (at most 64 keys of this context's size: ~1.4 MB each here)
+    big = obj(b"\x00" * (200 << 20), compr)
+    with pytest.raises(RuntimeError, match="inflates beyond the largest object"):
+        X.seal_load_galois_keys(big)
+    with pytest.raises(RuntimeError, match="inflates beyond the largest object"):
+        X.keyset().seal_load_relin_keys(big)
+    # a compressed NESTED array (never written by SEAL) is refused before anything is inflated
+    ct = fresh_cts(S, 1)[0]
+    words = np.ascontiguousarray(ct, dtype="<u8").reshape(-1)
+    nested = obj(struct.pack("<Q", words.size) + words.tobytes(), compr)
+    members = PID_DATA + struct.pack("<B", 0) + struct.pack("<QQQ", 2, S.n, X.L) + struct.pack("<d", 1.0) + struct.pack("<Q", 1) + nested
+    with pytest.raises(RuntimeError, match="nested object is compressed"):
+        X.seal_load_ciphertext(obj(members), out)
+
+
+def test_key_loads_are_all_or_nothing(api, emu_lib, mem, S):
+    """SEAL's load(context, ..) swaps the object in only on success: a GaloisKeys blob whose LAST key is bad (truncated table, foreign
+    shape, unreduced word) leaves the target set exactly as it was -- no earlier key of the blob has been uploaded"""
+    O = S.O
+    X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+    ks = X.keyset()
+    table = galois_table(S.gk)
+    good = kswitch_keys(PID_KEY, table, S.n, X.K)
+    idx = [i for i, e in enumerate(table) if e is not None]
+    bad_word = [None if e is None else e.copy() for e in table]
+    bad_word[idx[-1]][0, 0, 0, 3] = S.q[0]                 # not reduced
+    for blob, what in ((good[:len(good) - 4096], "truncated|exceeds the buffer"),
+                       (kswitch_keys(PID_KEY, bad_word, S.n, X.K), "not reduced"),
+                       (kswitch_keys(PID_KEY, table[:-1] + [S.rk[:-1]], S.n, X.K), "digits")):
+        if "truncated" in what:   # keep the header's size field consistent with the shortened buffer, so the table itself is short
+            blob = header(len(blob)) + blob[16:]
+        with pytest.raises(RuntimeError, match=what):
+            ks.seal_load_galois_keys(blob)
+        assert not any(ks.has_galois(int(e)) for e in S.gk.elts)
+        with pytest.raises(RuntimeError, match=what):
+            X.seal_load_galois_keys(blob)
+        assert not any(X.has_galois_key(int(e)) for e in S.gk.elts)
+    # and the good blob loads into a SET, which then drives rotations with exactly these keys
+    used, cnt = ks.seal_load_galois_keys(good)
+    assert used == len(good) and cnt == len(S.gk.elts) and not X.has_galois_key(int(S.gk.elts[0]))
+    ct = fresh_cts(S, 1, seed=5)[0]
+    out = mem.empty((1,) + O.ct_shape)
+    X.rotate_rows(mem.to_dev(ct[None]), 3, out, 1, gk=ks)
+    assert (mem.to_host(out)[0] == O.rotate_rows(ct, 3, S.gk)[0]).all()
+    with pytest.raises(RuntimeError, match="Galois key not present"):
+        X.rotate_rows(mem.to_dev(ct[None]), 3, out, 1)   # the default set is still empty
+    # SEAL 4.0.0's member order: scale (the double 1.0) THEN correction factor (the integer 1); the swapped order is refused
+    m = PID_DATA + struct.pack("<B", 0) + struct.pack("<QQQ", 2, S.n, X.L) + struct.pack("<Q", 1) + struct.pack("<d", 1.0)
+    words = np.ascontiguousarray(ct, dtype="<u8").reshape(-1)
+    swapped = obj(m + obj(struct.pack("<Q", words.size) + words.tobytes()))
+    with pytest.raises(RuntimeError, match="scale / correction factor"):
+        X.seal_load_ciphertext(swapped, mem.empty(O.ct_shape))

@@ -11,18 +11,19 @@ logn, q, t = 15, bench.Q_CONFIG2, 65537
 n, K, L = 1 << logn, 4, 3
 X = api.Context(logn, q, t)
 rng = np.random.default_rng(1)
-X.set_relin_key(bench.synthetic_keys(rng, q, n)); X.set_relin_key_slot(1, bench.synthetic_keys(rng, q, n))
-elts = set()
+csp_rk, analyst_gk = X.keyset(), X.keyset()   # the key objects the CSP names at CSP.cpp:306 and :312-316
+csp_rk.set_relin(bench.synthetic_keys(rng, q, n))
+elts = {2 * n - 1}
 g, gi = 3, pow(3, -1, 2 * n)
 for _ in range(logn - 1):
     elts.add(g); elts.add(gi); g, gi = g * g % (2 * n), gi * gi % (2 * n)
 for e in sorted(elts):
-    X.set_galois_key(e, bench.synthetic_keys(rng, q, n))
+    analyst_gk.set_galois(e, bench.synthetic_keys(rng, q, n))
 vi = torch.from_numpy(bench.synthetic_ct(rng, q, n, S * 10).view(np.int64)).cuda()
 w = torch.from_numpy(bench.synthetic_ct(rng, q, n, 10).view(np.int64)).cuda()
 out = torch.zeros_like(vi)
-X.fc_row(vi[:10], w, 10, 784, out[:10], 10, relin_slot=1)
+X.fc_row(vi[:10], w, 10, 784, out[:10], 10, rk=csp_rk, gk=analyst_gk)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-X.fc_row(vi, w, 10, 784, out, S * 10, relin_slot=1)
+X.fc_row(vi, w, 10, 784, out, S * 10, rk=csp_rk, gk=analyst_gk)
 torch.cuda.synchronize(); t1 = time.perf_counter()
 print(f"FC 784x10 on {S} samples: {1e3 * (t1 - t0) / S:.1f} ms/sample, fallbacks {X.query('fc_fallbacks')}")

@@ -29,7 +29,8 @@ buf = np.zeros(SL * WG, np.uint64)
 lib.hhe_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.hhe_debug_read_stamps(buf.ctypes.data, buf.size) == 0
 s = buf.reshape(WG, SL).astype(np.int64)
-nmain = (B * K * 64) // 64   # sampled key-switch workgroups of the last launch (every 64th of B*K*64)
+reps = int(os.environ.get('HHE_KS_REPS', '2'))
+nmain = ((B + reps - 1) // reps) * K   # sampled key-switch workgroups of the last launch (every 64th of groups*K*64); the first item of each is recorded
 main = s[:min(nmain, WG)]
 main = main[(main[:, 0] > 0) & (main[:, 16] > main[:, 0])]
 names = {1: "twiddle fill"}
