@@ -149,10 +149,13 @@ int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key_dptr, const uint6
 /* the same for a PASTA_SEAL constructed with the RelinKeys `rk` and the GaloisKeys `gk` (CSP.cpp:238-242: the analyst's) */
 int hhe_pasta3_transcipher_ks(hhe_ctx *c, const hhe_keyset *rk, const hhe_keyset *gk, const uint64_t *enc_key_dptr, const uint64_t *cw_hptr,
                               const uint32_t *ncw_hptr, const uint64_t *block_index_hptr, size_t B, int use_bsgs, uint64_t *out_dptr);
-/* drop cached per-block public tables (matrices depend only on (nonce, block index)).  The cache is unbounded and grows by
- * (4 x 128 x L + 4) x N words per distinct block counter on first use -- 384 MiB at N = 2^15, L = 3; 1.07 GiB at the
- * reference defaults N = 2^14, L = 8; the babystep-giantstep variant adds the same again -- so a caller that walks through
- * many block counters (long records) calls this between batches. */
+/* The per-block public tables (matrices depend only on (nonce, block index)) are built on first use and cached per block counter:
+ * (4 x 128 x L) x N words of multipliers, twice that with their Shoup quotients in the fused pipeline -- 768 MiB per counter at
+ * N = 2^15, L = 3; 1.07 / 2.1 GiB at the reference defaults N = 2^14, L = 8 -- and the babystep-giantstep variant adds (4 x 128 x L) x N.
+ * The cache is bounded: beyond `bytes` (default 32 GiB; HHE_BLOCK_CACHE_MB) the least recently used counters are dropped, never
+ * one the running call uses (a single call that needs more than the limit is served).  hhe_ctx_query("block_cache_bytes" /
+ * "block_cache_entries") report its state; hhe_pasta3_clear_block_cache drops everything. */
+int hhe_pasta3_set_block_cache_limit(hhe_ctx *c, size_t bytes);
 void hhe_pasta3_clear_block_cache(hhe_ctx *c);
 /* SEALZpCipher::mask (src/pasta/SEAL_Cipher.cpp:161-166): mask_vals_hptr[count], shared by the batch */
 int hhe_mask(hhe_ctx *c, const uint64_t *ct_dptr, const uint64_t *mask_vals_hptr, size_t count,

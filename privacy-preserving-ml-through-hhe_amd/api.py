@@ -35,7 +35,7 @@ _SYMBOLS = [
     "hhe_pasta3_block_randomness", "hhe_pasta3_plain_keystream", "hhe_pasta3_plain_crypt", "hhe_decrypt",
     "hhe_ctx_profile", "hhe_ctx_profile_read", "hhe_relinearize_slot",
     "hhe_seal_load_ciphertext", "hhe_seal_save_ciphertext", "hhe_seal_load_relin_keys", "hhe_seal_load_galois_keys",
-    "hhe_keyset_create", "hhe_keyset_destroy", "hhe_keyset_set_relin", "hhe_keyset_set_galois", "hhe_keyset_has_galois", "hhe_keyset_has_relin",
+    "hhe_pasta3_set_block_cache_limit", "hhe_keyset_create", "hhe_keyset_destroy", "hhe_keyset_set_relin", "hhe_keyset_set_galois", "hhe_keyset_has_galois", "hhe_keyset_has_relin",
     "hhe_apply_galois_ks", "hhe_rotate_rows_ks", "hhe_rotate_columns_ks", "hhe_relinearize_ks", "hhe_pasta3_transcipher_ks",
     "hhe_flatten_ks", "hhe_decompose_ks", "hhe_fc_row_ks", "hhe_seal_load_relin_keys_ks", "hhe_seal_load_galois_keys_ks",
 ]
@@ -268,6 +268,9 @@ class Context:
 
     def clear_block_cache(self):
         self.lib.hhe_pasta3_clear_block_cache(self.h)
+
+    def set_block_cache_limit(self, nbytes):
+        self._chk(self.lib.hhe_pasta3_set_block_cache_limit(self.h, C.c_size_t(nbytes)))
 
     def mask(self, ct, mask_vals, out, B):
         mv = np.ascontiguousarray(mask_vals, dtype=np.uint64)

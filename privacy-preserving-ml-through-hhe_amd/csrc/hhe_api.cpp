@@ -275,19 +275,38 @@ int ensure_feistel_mask(hhe_ctx *c)
     return HHE_OK;
 }
 
-// Public tables of one block counter, built on the device on first use.  Footprint per counter: (4 x 128 x L + 4) x N
-// words for `pdiag` (fused pipeline) or `diag` (op-by-op schedule, HHE_MATMUL=0) -- 384 MiB at N = 2^15, L = 3; the
-// babystep-giantstep variant adds the same again on its first use.  hhe_pasta3_clear_block_cache() releases them.
+void free_block(BlockTables &bt) { rt_free(bt.diag); rt_free(bt.pdiag); rt_free(bt.rc); rt_free(bt.bsgs); }
+// make room for `need` more bytes of block tables: the least recently used counters that the running call (c->block_call) does not
+// use are dropped while the cache would pass its limit.  A single call that needs more than the limit is served anyway.
+void evict_blocks(hhe_ctx *c, size_t need)
+{
+    while (c->block_bytes + need > c->block_cache_limit) {
+        auto victim = c->blocks.end();
+        for (auto it = c->blocks.begin(); it != c->blocks.end(); ++it)
+            if (it->second.last_call != c->block_call && (victim == c->blocks.end() || it->second.last_call < victim->second.last_call)) victim = it;
+        if (victim == c->blocks.end()) return;
+        sync_ctx(c);  // earlier calls have completed (every entry point waits for its work), but a caller's stream may lag
+        c->block_bytes -= victim->second.bytes;
+        free_block(victim->second);
+        c->blocks.erase(victim);
+    }
+}
+// Public tables of one block counter, built on the device on first use.  Footprint per counter: (4 x 128 x L) x N words of
+// multipliers -- twice that for `pdiag` with its Shoup quotients (fused pipeline; 768 MiB at N = 2^15, L = 3), once for `diag`
+// (op-by-op schedule, HHE_MATMUL=0) -- plus 4 N words of round constants; the babystep-giantstep variant adds (4 x 128 x L) x N on
+// its first use.  The cache is bounded (hhe_pasta3_set_block_cache_limit); hhe_pasta3_clear_block_cache() releases everything.
 int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
 {
     auto it = c->blocks.find(block);
-    if (it != c->blocks.end()) { *out = &it->second; return HHE_OK; }
+    if (it != c->blocks.end()) { it->second.last_call = c->block_call; *out = &it->second; return HHE_OK; }
     const size_t n = c->n, half = n / 2;
     const int L = c->L;
     const size_t ndiag = (size_t)(PASTA_R + 1) * PASTA_T;
     std::vector<u64> mats((size_t)(PASTA_R + 1) * 2 * PASTA_T * PASTA_T), rcs((size_t)(PASTA_R + 1) * 2 * PASTA_T);
     pasta3_block_randomness(c->t, PASTA_NONCE, block, mats.data(), rcs.data());
     const bool fused = c->matmul_mode == 1;
+    const size_t entry_bytes = (fused ? 2 : 1) * ndiag * L * n * 8 + (size_t)(PASTA_R + 1) * n * 8;
+    evict_blocks(c, entry_bytes);
     DevBuf d_mats(mats.size() * 8), d_rcs(rcs.size() * 8), slots(ndiag * n * 8), diag(ndiag * L * n * 8),
         rc((size_t)(PASTA_R + 1) * n * 8), pdiag(fused ? 2 * ndiag * L * n * 8 : 8);  // pdiag | its Shoup quotients
     if (!d_mats.p || !d_rcs.p || !slots.p || !diag.p || !rc.p || !pdiag.p) return dev_fail("block table alloc");
@@ -317,6 +336,9 @@ int ensure_block(hhe_ctx *c, u64 block, BlockTables **out)
     bt.rc = rc.release();
     if (fused) bt.pdiag = pdiag.release();  // the fused pipeline reads only pdiag: diag is dropped with this scope
     else bt.diag = diag.release();
+    bt.bytes = entry_bytes;
+    bt.last_call = c->block_call;
+    c->block_bytes += entry_bytes;
     auto ins = c->blocks.emplace(block, bt);
     *out = &ins.first->second;
     return HHE_OK;
@@ -331,6 +353,7 @@ int ensure_bsgs_tables(hhe_ctx *c, u64 block, BlockTables *bt)
     const size_t ndiag = (size_t)(PASTA_R + 1) * PASTA_T;
     std::vector<u64> mats((size_t)(PASTA_R + 1) * 2 * PASTA_T * PASTA_T), rcs((size_t)(PASTA_R + 1) * 2 * PASTA_T);
     pasta3_block_randomness(c->t, PASTA_NONCE, block, mats.data(), rcs.data());
+    evict_blocks(c, ndiag * L * n * 8);
     DevBuf d_mats(mats.size() * 8), slots(ndiag * n * 8), bsgs(ndiag * L * n * 8);
     if (!d_mats.p || !slots.p || !bsgs.p) return dev_fail("bsgs table alloc");
     rt_h2d(d_mats.p, mats.data(), mats.size() * 8, c->w->stream);
@@ -343,6 +366,8 @@ int ensure_bsgs_tables(hhe_ctx *c, u64 block, BlockTables *bt)
     op_lift_ntt(c, slots.w(), ndiag, bsgs.w());
     if (rt_sync(c->w->stream)) return dev_fail("bsgs tables");
     bt->bsgs = bsgs.release();
+    bt->bytes += ndiag * L * n * 8;
+    c->block_bytes += ndiag * L * n * 8;
     return HHE_OK;
 }
 
@@ -770,6 +795,7 @@ static int transcipher_impl(hhe_ctx *c, const uint64_t *enc_key, const uint64_t 
     c->w = &main;
     int rc;
     if ((rc = ensure_feistel_mask(c))) return rc;
+    ++c->block_call;
     // per-item public tables
     std::vector<const u64 *> ptrs(2 * B);
     std::vector<u64> cwp(B * PASTA_T, 0);
@@ -840,6 +866,15 @@ extern "C" int hhe_pasta3_transcipher(hhe_ctx *c, const uint64_t *enc_key, const
     return hhe_pasta3_transcipher_ks(c, nullptr, nullptr, enc_key, cw, ncw, block_index, B, use_bsgs, out);
 }
 
+extern "C" int hhe_pasta3_set_block_cache_limit(hhe_ctx *c, size_t bytes)
+{
+    HHE_LOCK(c);
+    if (!c) return fail(HHE_ERR_INVALID, "hhe_pasta3_set_block_cache_limit: null context");
+    c->block_cache_limit = bytes;
+    ++c->block_call;   // no transciphering call is running (the context is locked): nothing is pinned
+    evict_blocks(c, 0);
+    return HHE_OK;
+}
 extern "C" int hhe_mask(hhe_ctx *c, const uint64_t *ct, const uint64_t *mask_vals, size_t count, uint64_t *out, size_t B)
 {
     HHE_LOCK(c);

@@ -330,6 +330,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
         c->ksc.hq2[j] = 2 * dq[j] + nt_mulmod(kf.half_mod[j], kf.qsp_inv[j], dq[j]);
     }
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
+    if (const char *e = getenv("HHE_BLOCK_CACHE_MB")) c->block_cache_limit = (size_t)std::max(0, atoi(e)) << 20;
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
     if (const char *e = getenv("HHE_FC_SHARED")) c->fc_shared = atoi(e);
     if (const char *e = getenv("HHE_FC_CHUNK")) c->fc_chunk = (size_t)std::max(0, atoi(e));
@@ -410,6 +411,7 @@ extern "C" void hhe_pasta3_clear_block_cache(hhe_ctx *c)
     sync_ctx(c);
     for (auto &kv : c->blocks) { rt_free(kv.second.diag); rt_free(kv.second.pdiag); rt_free(kv.second.rc); rt_free(kv.second.bsgs); }
     c->blocks.clear();
+    c->block_bytes = 0;
 }
 
 extern "C" void hhe_ctx_destroy(hhe_ctx *c)
@@ -515,6 +517,8 @@ extern "C" uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i)
     if (w == "delta" && i >= 0 && i < c->L) return c->apl.delta[i];
     if (w == "slot_map" && i >= 0 && (size_t)i < c->n) return c->slot_map[i];
     if (w == "fc_fallbacks") return c->fc_fallbacks;
+    if (w == "block_cache_bytes") return c->block_bytes;
+    if (w == "block_cache_entries") return c->blocks.size();
     return 0;
 }
 

@@ -12,6 +12,8 @@ struct BlockTables {   // public per-(nonce, block index) data of one PASTA bloc
     u64 *rc = nullptr;    // [4][N] round-constant plaintexts (coefficients mod t)
     u64 *pdiag = nullptr; // diag composed with the NTT-domain index map of rotate_rows(-1): pdiag[x] = diag[pi(x)]
     u64 *bsgs = nullptr;  // [4][128][L][N] babystep-giantstep variant of diag (lazy)
+    size_t bytes = 0;     // device footprint of this entry
+    u64 last_call = 0;    // the transciphering call that used it last (block_call): entries of the running call are never evicted
 };
 
 constexpr int HHE_MAX_STREAMS = 4;
@@ -115,6 +117,9 @@ struct hhe_ctx {
 
     // PASTA public tables
     std::map<u64, BlockTables> blocks;
+    size_t block_bytes = 0;                      // footprint of all cached block tables
+    size_t block_cache_limit = (size_t)32 << 30; // bytes (hhe_pasta3_set_block_cache_limit, HHE_BLOCK_CACHE_MB): beyond it the least recently used counters go
+    u64 block_call = 0;                          // running number of the transciphering calls
     u64 *d_feistel_mask = nullptr;  // [L][N] NTT form of the sbox_feistel mask plaintext
 
     // execution lanes: lane 0 runs on the caller's stream (generic ops); lanes 1.. are internal streams that

@@ -750,7 +750,9 @@ HD void ks_corr_body(const KsCorrArgs &a, size_t gid)
 #define KSROW_TL 9
 #endif
 constexpr int KSROW_TILE_LOG = KSROW_TL;                             // points per tile of this kernel (log2)
-constexpr int KSROW_THREADS = (1 << KSROW_TILE_LOG) / 8;             // 8 points per lane: 2 x 8 lazy sums + a radix-8 round fit the 128-VGPR budget of 4 waves per SIMD
+constexpr int KSROW_THREADS = (1 << KSROW_TILE_LOG) / 8;             // 8 points per lane: 2 x 8 lazy sums + a radix-8 round fit the 128-VGPR budget of 4 waves per SIMD.
+                                                                     // (4 points per lane on 256-point tiles, radix-4 rounds: 90 VGPRs, 5-6 waves per SIMD -- measured 481-484 us per
+                                                                     // launch against 433: one more LDS round trip per transform and twice the per-workgroup start-up)
 constexpr int KSROW_SCHED = 512;                                     // NttSched selector of the 8-points-per-lane (radix-8/4) schedules
 constexpr int KSROW_NP = (1 << KSROW_TILE_LOG) / 2 / KSROW_THREADS;  // pairs per lane of a tile
 constexpr int KSROW_LDS = (1 << KSROW_TILE_LOG) + 256;  // words: M rows of pitch C + 1 = 2^TL + M, M <= 256

@@ -241,6 +241,31 @@ def test_config5_n65536_six_primes_rotation_chain_and_multiply(orc, api, lib, me
     assert (h[0] == O.transcipher_block(enc_key, S.rk, S.gk, cw[0], 0)).all() and (h[1] == h[0]).all()
 
 
+def test_config5_rotation_chain_128_steps(orc, api, lib, mem):
+    """BASELINE config 5's chain at depth: 128 steps of rotate_rows(-1) at N = 2^16, 6 x 60-bit primes on two ciphertexts -- every step's
+    rounding feeds the next, so any deviation in the generic key switch (digit loads through the Galois map, fused row kernel with both
+    sums inverse-transformed, mod-down in the store of the last inverse pass) shows in the words.  Compared with the SHA-256 of the
+    oracle's words after 4, 64 and 128 steps (tests/golden/config5_chain.json, computed once on the CPU: make_config5_chain.py)."""
+    import hashlib
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5_chain.json")))
+    t = 8088322049
+    S = Setup(orc, 16, [60] * 6, t=t)
+    O = S.O
+    X = api.Context(S.logn, S.q, t, lib=lib)
+    S.load_keys(X)
+    rng = np.random.default_rng(5)
+    cts = np.stack([O.encrypt(S.pk, O.encode(rng.integers(0, 1 << 30, O.n)), 40 + b) for b in range(2)])
+    src, dst = mem.to_dev(cts), mem.empty(cts.shape)
+    for step in range(1, 129):
+        X.rotate_rows(src, -1, dst, 2)
+        src, dst = dst, src
+        if str(step) in fx["steps"]:
+            h = mem.to_host(src)
+            assert [hashlib.sha256(np.ascontiguousarray(h[b]).tobytes()).hexdigest() for b in range(2)] == fx["steps"][str(step)], step
+
+
 def test_babystep_giantstep_variant(orc, api, lib, mem):
     S = Setup(orc, 10, [50] * 9, extra_steps=[-16 * k for k in range(1, 8)])
     X = api.Context(S.logn, S.q, S.t, lib=lib)

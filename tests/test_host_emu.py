@@ -409,3 +409,39 @@ def test_matmul_loop_adversarial_residues(orc, api, emu_lib, mem, pattern):
     S = Setup(orc, 12, [60, 60, 60])
     X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
     pc.check_matmul_adversarial(X, S, orc, mem, pattern)
+
+
+def test_block_table_cache_is_bounded_lru(orc, api, emu_lib, mem, small):
+    """the per-block public tables are cached per block counter; the cache holds at most its byte limit: least recently used counters
+    go first, never one the running call uses, and an evicted counter is rebuilt with the same words"""
+    X = api.Context(small.logn, small.q, small.t, lib=emu_lib)
+    small.load_keys(X)
+    pt = [(3 * i + 1) % 256 for i in range(128)]
+    out = mem.empty((1,) + small.O.ct_shape)
+
+    def run(ctr):
+        ks = orc.pasta_keystream(small.t, small.key, ctr)
+        cw = ((np.array(pt, dtype=np.uint64) + ks) % small.t).reshape(1, 128)
+        X.transcipher(mem.to_dev(small.enc_key), cw, [128], [ctr], out)
+        return mem.to_host(out)[0].copy(), cw
+
+    first, cw0 = run(0)
+    per = X.query("block_cache_bytes")
+    assert per > 0 and X.query("block_cache_entries") == 1
+    X.set_block_cache_limit(2 * per)
+    run(1)
+    run(2)                       # counter 0 is the least recently used: dropped
+    assert X.query("block_cache_entries") == 2 and X.query("block_cache_bytes") == 2 * per
+    run(1)                       # refresh 1; then 3 evicts 2
+    run(3)
+    assert X.query("block_cache_entries") == 2
+    again, _ = run(0)            # rebuilt: identical words
+    assert (again == first).all() and (first == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cw0[0], 0)).all()
+    # one call that needs more counters than the limit holds is served (its own tables are pinned while it runs)
+    cws = np.concatenate([run(c)[1] for c in (4, 5, 6)])
+    out3 = mem.empty((3,) + small.O.ct_shape)
+    X.transcipher(mem.to_dev(small.enc_key), cws, [128] * 3, [4, 5, 6], out3)
+    assert X.query("block_cache_entries") == 3
+    assert (mem.to_host(out3)[2] == small.O.transcipher_block(small.enc_key, small.rk, small.gk, cws[2], 6)).all()
+    X.set_block_cache_limit(0)
+    assert X.query("block_cache_entries") == 0 and X.query("block_cache_bytes") == 0
