@@ -21,6 +21,15 @@ for r in (1, 4):
             name = row.get("Name", "")
             if any(k in name for k in ("hipMemcpy", "hipMalloc", "hipFree", "hipLaunchKernel", "hipModuleLaunch")):
                 out.write("  %-40s calls %8s  total %12s ns\n" % (name, row.get("Calls"), row.get("TotalDurationNs")))
+    for f in glob.glob("$f/ks%d/**/*memory_copy_trace.csv" % r, recursive=True)[:1]:
+        tot = {}
+        for row in csv.DictReader(open(f)):
+            d = row.get("Direction", "?")
+            b = row.get("Bytes") or row.get("Size") or "0"
+            n, s = tot.get(d, (0, 0))
+            tot[d] = (n + 1, s + int(float(b)))
+        for d, (n, s) in sorted(tot.items()):
+            out.write("  copies %-28s count %6d  bytes %14d\n" % (d, n, s))
 out.close()
 print(open("$p/r3_hip_api_keyset_requests.txt").read())
 PY
