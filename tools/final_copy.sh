@@ -25,11 +25,10 @@ for r in (1, 4):
         tot = {}
         for row in csv.DictReader(open(f)):
             d = row.get("Direction", "?")
-            b = row.get("Bytes") or row.get("Size") or "0"
             n, s = tot.get(d, (0, 0))
-            tot[d] = (n + 1, s + int(float(b)))
+            tot[d] = (n + 1, s + int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
         for d, (n, s) in sorted(tot.items()):
-            out.write("  copies %-28s count %6d  bytes %14d\n" % (d, n, s))
+            out.write("  copy-engine transfers %-28s count %6d  busy %12d ns   (this rocprofv3's trace has no size column; the count and the busy time do not grow with the requests)\n" % (d, n, s))
 out.close()
 print(open("$p/r3_hip_api_keyset_requests.txt").read())
 PY

@@ -53,3 +53,11 @@ for kind, sel in (("data limbs (J < L)", main[:, 11] == 0), ("special limb", mai
         prev = i
 span = main[:, 16].max() - main[:, 0].min()
 print(f"launch span (first start to last end among sampled) {span} cycles; sum of per-wg totals / span = {(main[:, 16] - main[:, 0]).sum() / span:.1f} sampled wgs in flight on average (x64 for all)")
+# where the short c0 tiles (last in the grid) sit in the launch: their share of the kernel's duration
+c0 = s[min(nmain, WG):]
+c0 = c0[(c0[:, 0] > 0) & (c0[:, 16] > c0[:, 0])]
+if len(c0):
+    t0 = min(main[:, 0].min(), c0[:, 0].min())
+    print(f"c0 tiles sampled {len(c0)}: workgroup life median {np.median(c0[:, 16] - c0[:, 0]):.0f} cycles (p10 {np.percentile(c0[:, 16] - c0[:, 0], 10):.0f}, p90 {np.percentile(c0[:, 16] - c0[:, 0], 90):.0f})")
+    print(f"relative to the first sampled start: key-switch workgroups start {main[:, 0].min() - t0}..{main[:, 0].max() - t0}, end ..{main[:, 16].max() - t0}; "
+          f"c0 tiles start {c0[:, 0].min() - t0}..{c0[:, 0].max() - t0} (median {np.median(c0[:, 0]) - t0:.0f}), end ..{c0[:, 16].max() - t0}")
