@@ -274,6 +274,7 @@ void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s)
 #ifdef HHE_STAMPS
 constexpr int STAMP_SLOTS = 24, STAMP_WGS = 4096;
 __device__ u64 g_ks_stamps[STAMP_WGS * STAMP_SLOTS];
+__device__ int g_ks_stamp_launch;  // 1 while the ONE launch HHE_STAMP_LAUNCH selects runs (set from the host, in stream order)
 // the clock values stay in scalar registers until the workgroup is done (a store per stamp would make the wave wait for all its
 // outstanding vector memory operations at every phase boundary and distort the timeline it is meant to show)
 #define KS_STAMP(i) do { if (st_rec) stamps_[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -308,14 +309,23 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_row_kernel(NttA
     // c0 last: 292.0 /s on one box; alternating the two kinds: 2 % slower than either)
     const unsigned nmain = (unsigned)(x.B * x.K) << a.tiles_log;
 #ifdef HHE_STAMPS
-    const bool stamp_on = (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < STAMP_WGS;
+    const bool stamp_on = (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < STAMP_WGS && g_ks_stamp_launch;
     const unsigned stamp_wg = blockIdx.x >> 6;
     u64 stamps_[17];
 #pragma unroll
     for (int i_ = 0; i_ < 17; i_++) stamps_[i_] = 0;
 #endif
+    // Block -> (item, limb, tile): the ITEM index runs fastest within groups of eight (limb, tile) units, and the unit's position in its
+    // group is the block's XCD (blocks are dealt round-robin to the 8 XCDs).  Every item's workgroup for one (limb, tile) -- the readers of
+    // the same 16-KB key slices and twiddles -- runs on the same XCD at about the same time, so a key is fetched into each L2 once per
+    // launch instead of once per item (config 5: 63 MB of key + quotients against 4 MB of L2 per XCD; the item-major order read 2.7 GB per launch).
+    const unsigned tmask = (1u << a.tiles_log) - 1;
     if (blockIdx.x >= nmain) {
-        const unsigned cb = blockIdx.x - nmain;
+        unsigned cb = blockIdx.x - nmain;
+        if (c0.count == x.B * x.L) {   // (item b, limb j) polynomials: same order as the key-switch tiles
+            const unsigned r = cb >> 3, u = (r / (unsigned)x.B) * 8 + (cb & 7);
+            cb = (((r % (unsigned)x.B) * x.L + (u >> a.tiles_log)) << a.tiles_log) | (u & tmask);
+        }
 #ifdef HHE_STAMPS
         const bool st_rec = true;
 #endif
@@ -325,9 +335,8 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_row_kernel(NttA
         KS_STAMP_FLUSH();
         return;
     }
-    const unsigned bid = blockIdx.x;
-    const int bx = (int)(bid & ((1u << a.tiles_log) - 1)), y = (int)(bid >> a.tiles_log);
-    const int b = y / x.K, J = y % x.K, tid = threadIdx.x;
+    const unsigned rr = blockIdx.x >> 3, uu = (rr / (unsigned)x.B) * 8 + (blockIdx.x & 7);
+    const int b = (int)(rr % (unsigned)x.B), J = (int)(uu >> a.tiles_log), bx = (int)(uu & tmask), tid = threadIdx.x;
     const size_t n = (size_t)1 << a.logn;
     {
 #ifdef HHE_STAMPS
@@ -401,6 +410,15 @@ int k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_st
     else { memset(&c0, 0, sizeof(c0)); }
     dim3 grid((unsigned)(((size_t)x.B * x.K + c0.count) << a.tiles_log));
     hipStream_t st = (hipStream_t)s;
+#ifdef HHE_STAMPS
+    {
+        static const int flags[2] = {0, 1};
+        static int launch = 0;
+        const char *e = getenv("HHE_STAMP_LAUNCH");
+        const int on = launch++ == (e ? atoi(e) : 300);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ks_stamp_launch), &flags[on], sizeof(int), 0, hipMemcpyHostToDevice, st);
+    }
+#endif
     switch (n2) {
     case 6: hipLaunchKernelGGL((ks_row_kernel<6>), grid, dim3(KSROW_THREADS), 0, st, a, x, c0); break;
     case 7: hipLaunchKernelGGL((ks_row_kernel<7>), grid, dim3(KSROW_THREADS), 0, st, a, x, c0); break;

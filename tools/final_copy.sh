@@ -8,6 +8,7 @@ cp $f/bench_default.json $p/r3_bench_default.json
 cp $f/bench_mnist_e2e.json $p/r3_bench_mnist_e2e.json
 cp $f/c5/out_kernel_stats.csv $p/r3_config5_kernel_stats.csv
 cp $f/fc/out_kernel_stats.csv $p/r3_fc_kernel_stats.csv
+cp $f/c5pmc/summary.json $p/r3_config5_pmc_summary.json
 python3 - <<PY
 import csv, glob
 out = open("$p/r3_hip_api_keyset_requests.txt", "w")

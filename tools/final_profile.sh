@@ -14,6 +14,7 @@ timeout -k 10 800 python3 $root/bench.py > $out/bench_default.json 2> $out/bench
 timeout -k 10 300 python3 $root/bench.py --workload mnist-e2e --steps 1 --warmup 1 > $out/bench_mnist_e2e.json 2> $out/bench_mnist_e2e.err || exit 1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $out/c5 -o out --output-format csv -- python3 $root/tools/config5_only.py 64 32 > $out/c5.log 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $out/fc -o out --output-format csv -- python3 $root/tools/fc_only.py 16 > $out/fc.log 2>&1 )
+bash $root/tools/pmc_config5.sh final/c5pmc > $out/c5pmc.log 2>&1
 for r in 1 4; do
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --hip-trace --memory-copy-trace --stats -d $out/ks$r -o out --output-format csv -- python3 $root/tools/keyset_requests.py $r > $out/ks$r.log 2>&1 )
 done

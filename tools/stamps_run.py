@@ -29,8 +29,10 @@ buf = np.zeros(SL * WG, np.uint64)
 lib.hhe_debug_read_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.hhe_debug_read_stamps(buf.ctypes.data, buf.size) == 0
 s = buf.reshape(WG, SL).astype(np.int64)
+if len(sys.argv) > 2:
+    np.save(sys.argv[2], s)
 reps = int(os.environ.get('HHE_KS_REPS', '2'))
-nmain = ((B + reps - 1) // reps) * K   # sampled key-switch workgroups of the last launch (every 64th of groups*K*64); the first item of each is recorded
+nmain = B * K   # sampled key-switch workgroups: every 64th of B*K*64 tiles
 main = s[:min(nmain, WG)]
 main = main[(main[:, 0] > 0) & (main[:, 16] > main[:, 0])]
 names = {1: "twiddle fill"}
@@ -53,11 +55,14 @@ for kind, sel in (("data limbs (J < L)", main[:, 11] == 0), ("special limb", mai
         prev = i
 span = main[:, 16].max() - main[:, 0].min()
 print(f"launch span (first start to last end among sampled) {span} cycles; sum of per-wg totals / span = {(main[:, 16] - main[:, 0]).sum() / span:.1f} sampled wgs in flight on average (x64 for all)")
-# where the short c0 tiles (last in the grid) sit in the launch: their share of the kernel's duration
+# where the short c0 tiles (last in the grid) sit in the launch: their share of the kernel's duration (the library records ONE
+# launch, HHE_STAMP_LAUNCH, default the 300th ks_row launch of the process: a middle step of the second call)
 c0 = s[min(nmain, WG):]
 c0 = c0[(c0[:, 0] > 0) & (c0[:, 16] > c0[:, 0])]
 if len(c0):
     t0 = min(main[:, 0].min(), c0[:, 0].min())
-    print(f"c0 tiles sampled {len(c0)}: workgroup life median {np.median(c0[:, 16] - c0[:, 0]):.0f} cycles (p10 {np.percentile(c0[:, 16] - c0[:, 0], 10):.0f}, p90 {np.percentile(c0[:, 16] - c0[:, 0], 90):.0f})")
-    print(f"relative to the first sampled start: key-switch workgroups start {main[:, 0].min() - t0}..{main[:, 0].max() - t0}, end ..{main[:, 16].max() - t0}; "
-          f"c0 tiles start {c0[:, 0].min() - t0}..{c0[:, 0].max() - t0} (median {np.median(c0[:, 0]) - t0:.0f}), end ..{c0[:, 16].max() - t0}")
+    print(f"{len(main)} key-switch workgroups sampled: start {main[:, 0].min() - t0}..{main[:, 0].max() - t0}, last end {main[:, 16].max() - t0}")
+    print(f"{len(c0)} c0 tiles sampled: life median {np.median(c0[:, 16] - c0[:, 0]):.0f} cycles (p10 {np.percentile(c0[:, 16] - c0[:, 0], 10):.0f}, p90 {np.percentile(c0[:, 16] - c0[:, 0], 90):.0f}), "
+          f"start {c0[:, 0].min() - t0}..{c0[:, 0].max() - t0} (median {np.median(c0[:, 0]) - t0:.0f}), last end {c0[:, 16].max() - t0}")
+    e = np.sort(np.concatenate([main[:, 16], c0[:, 16]])) - t0
+    print("ends of all sampled workgroups, deciles:", [int(v) for v in np.percentile(e, range(0, 101, 10))])
