@@ -997,8 +997,23 @@ struct NafNode {
     std::vector<int> kids;
 };
 struct FcLeafAcc {  // sums over the leaves of the trie (DESIGN.md "FC rotation trie"): accS in the NTT domain, accH in the
-    u64 *accS, *accH, *rscr;  // coefficient domain (rounding terms + q_sp * galois(c0), added by the RACC epilogue)
+    u64 *accS, *accH, *rscr;  // coefficient domain (rounding terms + q_sp * galois(c0), added by leaf_round_kernel)
 };
+// rounding terms of one leaf key switch: inverse transform of the special limb (r = INTT(S_k[special]) + half) into acc.rscr, then the
+// element-wise sums half_j - (r mod q_j) (+ q_sp * galois(c0) for k = 0) into acc.accH
+static void fc_leaf_round(hhe_ctx *c, const u64 *S, const u64 *parent, u32 einv, const FcLeafAcc &acc, size_t B)
+{
+    const int L = c->L, K = c->K;
+    const size_t n = c->n, ln = (size_t)L * n;
+    NttArgs r = ntt_args(c, S + (size_t)(K - 1) * n, acc.rscr, B * 2, K - 1, 1);
+    r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RSP;
+    k_ntt(r, true, c->w->stream);
+    LeafRoundArgs lr;
+    memset(&lr, 0, sizeof(lr));
+    lr.r = acc.rscr; lr.accH = acc.accH; lr.base = parent; lr.base_stride = 2 * ln; lr.mods = c->d_mods; lr.logn = c->logn;
+    lr.B = (int)B; lr.L = L; lr.gal_einv = einv; lr.ks = c->ksc;
+    k_leaf_round(lr, c->w->stream);
+}
 // A leaf's ciphertext is only ever added into the result.  Key switching is linear up to the rounding term, so for
 // leaves the inverse transforms of S_k[j] are postponed: sum S_k[j] over all leaves in the NTT domain, sum the rounding
 // terms half_j - (r_k mod q_j) and galois(c0) in the coefficient domain, inverse-transform once (14 instead of 20
@@ -1013,7 +1028,7 @@ int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t
     memset(&g, 0, sizeof(g));
     g.mods = c->d_mods; g.logn = c->logn; g.count = (int)(B * L); g.L = L; g.einv = (u32)nt_invmod(elt, 2 * n);
     g.in_item_stride = 2 * ln; g.out_item_stride = ln;
-    g.in = parent + ln; g.out = c->w->ws_d; g.accumulate = 0;  // galois(c0) joins the sums inside the RACC epilogue below
+    g.in = parent + ln; g.out = c->w->ws_d; g.accumulate = 0;  // galois(c0) joins the sums inside leaf_round_kernel below
     k_galois(g, c->w->stream);
     NttArgs a = ntt_args(c, c->w->ws_d, c->w->ws_T, B * L * K, 0, K);
     a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
@@ -1024,10 +1039,7 @@ int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t
     m.T = c->w->ws_T; m.key = it->second; m.S = c->w->ws_S; m.s_acc = acc.accS; m.mods = c->d_mods; m.logn = c->logn;
     m.B = (int)B; m.L = L; m.K = K;
     k_ks_mac(m, c->w->stream);
-    NttArgs r = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, acc.rscr, B * 2, K - 1, 1);
-    r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RACC; r.acc = acc.accH;
-    r.aux_in = parent; r.base_stride = 2 * ln; r.gal_einv = (u32)nt_invmod(elt, 2 * n);
-    k_ntt(r, true, c->w->stream);
+    fc_leaf_round(c, c->w->ws_S, parent, (u32)nt_invmod(elt, 2 * n), acc, B);
     return HHE_OK;
 }
 // ---- shared digits (DESIGN.md "FC rotation trie", step 3) ----
@@ -1088,7 +1100,7 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
     if (rc) return rc;
     const int L = c->L, K = c->K;
     const size_t n = c->n, ln = (size_t)L * n;
-    const u32 einv = (u32)nt_invmod(elt, 2 * n);  // galois(c0) is gathered inside the epilogues (RACC for leaves, KSF otherwise)
+    const u32 einv = (u32)nt_invmod(elt, 2 * n);  // galois(c0) is gathered on the fly (leaf_round_kernel for leaves, the KSF epilogue otherwise)
     KsMacArgs m;
     memset(&m, 0, sizeof(m));
     m.T = tp; m.key = it->second; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
@@ -1098,10 +1110,7 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
     else m.S_sp = Usp;
     k_ks_mac(m, c->w->stream);
     if (leaf) {
-        NttArgs r = ntt_args(c, c->w->ws_S + (size_t)(K - 1) * n, leaf->rscr, B * 2, K - 1, 1);
-        r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RACC; r.acc = leaf->accH;
-        r.aux_in = parent; r.base_stride = 2 * ln; r.gal_einv = einv;
-        k_ntt(r, true, c->w->stream);
+        fc_leaf_round(c, c->w->ws_S, parent, einv, *leaf, B);
         return HHE_OK;
     }
     // all 2K sums are inverse-transformed; the mod-down rides in the store of the data limbs' last pass (STORE_KSF)

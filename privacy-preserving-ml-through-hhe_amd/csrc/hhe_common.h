@@ -80,7 +80,6 @@ enum NttStoreOp {
     STORE_RSP = 5,         // inv (special limb): v + floor(q_sp/2) mod q_sp
     STORE_KS1 = 6,         // inv: (v - r_1 + half) * q_sp^-1, written through the Galois map into aux_out
     STORE_KS0 = 7,         // fwd: NTT-domain key-switch finish of c0 + permuted-frame diagonal MAC
-    STORE_RACC = 9,        // inv (special limb): r = v + half mod q_sp, then acc[b][k][j] += half_j - (r mod q_j) for every data limb j
     STORE_KSF = 10,        // inv, polys [B][2][L]: generic key-switch finish (v - r_k + half) * q_sp^-1 (+ base poly k) into aux_out
     STORE_LAZY = 8         // fwd: leave the result in the lazy range [0,4q) (consumer reduces: key-switch inner product)
 };
@@ -131,7 +130,7 @@ struct NttArgs {
     // fused key-switch epilogues (matmul pipeline)
     int L, K;
     u32 gal_elt;        // KS1: coefficient-domain Galois element (0 = identity); KS0: NTT-domain element
-    u32 gal_einv;       // KSF / RACC: > 0 => the base / the c0 term is galois(c0) gathered on the fly: elt^-1 mod 2N (aux_in = the un-rotated ciphertexts)
+    u32 gal_einv;       // KSF: > 0 => the base is galois(c0) gathered on the fly: elt^-1 mod 2N (aux_in = the un-rotated ciphertexts)
     const u64 *aux_r;   // KS1 / KSF: r [B][2][N] (KS1: poly 1);  KS0: S [B][2][K][N] (poly 0, limb j)
     const u64 *aux_in;  // KS0: c0 (NTT form) of the current state [B][L][N];  KSF: base ciphertexts (item b at aux_in + b * base_stride) or null
     u64 *aux_out;       // KS1: d [B][L][N];  KS0: c0 (NTT form) of the next state [B][L][N];  KSF: out [B][2][L][N]
@@ -237,6 +236,17 @@ struct LeafSumArgs {  // out[b][k][j] += qsp_inv_j * (accS[b][k][j] (INTT'd) + a
     u64 *out;         // [B][2][L][N]
     const ModDev *mods;
     int logn, B, L;
+    KsConsts ks;
+};
+
+struct LeafRoundArgs {  // accH[b][k][j] += half_j - (r[b][k] mod q_j) (+ q_sp * galois(c0_b)[j] for k = 0): one leaf key switch of the FC trie
+    const u64 *r;      // [B][2][N]: INTT(S_k[special]) + floor(q_sp/2) mod q_sp (the STORE_RSP result)
+    u64 *accH;         // [B][2][L][N]
+    const u64 *base;   // un-rotated parent ciphertexts (item b at base + b * base_stride, c0 limbs first); read through the Galois map
+    size_t base_stride;
+    const ModDev *mods;
+    int logn, B, L;
+    u32 gal_einv;      // elt^-1 mod 2N
     KsConsts ks;
 };
 

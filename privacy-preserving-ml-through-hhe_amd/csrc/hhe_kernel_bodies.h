@@ -386,24 +386,8 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
         for (int k = 0; k < 2; k++) {
             v[k] = csub(shoup_lazy_n(v[k], st ? m.ninv_t : m.ninv, st ? m.ninv_t_s : m.ninv_s, m.nq), m.nq);
         }
-        if (a.store_op == STORE_RSP || a.store_op == STORE_RACC) { v[0] = addmod(v[0], a.ks.half, q); v[1] = addmod(v[1], a.ks.half, q); }
-        if (a.store_op == STORE_RACC) {  // poly = (item, k): rounding terms of a leaf key switch, summed per data limb
-            for (int j = 0; j < a.L; j++) {
-                const ModDev mj = mod_at(a.mods, j);
-                u64 *ap = a.acc + ((size_t)g.poly * a.L + j) * g.n + gi;
-                U2 ac = ld2(ap);
-                ac.a = addmod(ac.a, submod(a.ks.half_mod[j], reduce64(v[0], mj), mj.q), mj.q);
-                ac.b = addmod(ac.b, submod(a.ks.half_mod[j], reduce64(v[1], mj), mj.q), mj.q);
-                if (a.gal_einv && !(g.poly & 1)) {  // k = 0: + q_sp * galois(c0)[j] (the sum is multiplied by q_sp^-1 when it is closed)
-                    const U2 c0 = ld2_galois(a.aux_in + (size_t)(g.poly >> 1) * a.base_stride + (size_t)j * g.n, (u32)gi, a.logn, a.gal_einv, mj.q);
-                    ac.a = addmod(ac.a, shoup_mul(c0.a, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
-                    ac.b = addmod(ac.b, shoup_mul(c0.b, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
-                }
-                st2(ap, ac);
-            }
-            return;
-        }
-        else if (a.store_op == STORE_KSF) {  // Evaluator::switch_key_inplace mod-down, poly = (item, k, j)
+        if (a.store_op == STORE_RSP) { v[0] = addmod(v[0], a.ks.half, q); v[1] = addmod(v[1], a.ks.half, q); }
+        if (a.store_op == STORE_KSF) {  // Evaluator::switch_key_inplace mod-down, poly = (item, k, j)
             const int j = g.poly % a.L;
             const bool base = (a.base_mask >> ((g.poly / a.L) & 1)) & 1;
             const u64 rr[2] = {pre.s.a, pre.s.b}, bb[2] = {pre.d.a, pre.d.b};
@@ -928,6 +912,49 @@ HD void leaf_sum_body(const LeafSumArgs &a, size_t gid)
     u64 v = addmod(a.accS[gid], a.accH[gid], m.q);
     v = shoup_mul(v, a.ks.qsp_inv[j], a.ks.qsp_inv_s[j], m.q);
     a.out[gid] = addmod(a.out[gid], v, m.q);
+}
+
+// Rounding terms of a leaf key switch of the FC rotation trie, element-wise: gid over [B][2][N/2], two adjacent coefficients per lane.
+// Every load of a lane (r, the L sums, the L Galois-mapped c0 words) is requested before its first store.  This was the epilogue of
+// the special limb's last inverse pass until round 3: there every limb's read-modify-write sat behind the previous limb's store in the
+// wave's in-order memory counter, 24 dependent round trips per lane and 355 us per launch at 2.2 TB/s.
+template <int JC>
+HD void leaf_round_limbs(const LeafRoundArgs &a, size_t bk, size_t i, int j0, const U2 r, bool with_c0)
+{
+    const size_t n = (size_t)1 << a.logn;
+    U2 ac[JC], c0[JC];
+#pragma unroll
+    for (int jj = 0; jj < JC; jj++) {
+        const int j = j0 + jj;
+        if (j < a.L) {
+            ac[jj] = ld2(a.accH + (bk * a.L + j) * n + i);
+            if (with_c0) c0[jj] = ld2_galois(a.base + (bk >> 1) * a.base_stride + (size_t)j * n, (u32)i, a.logn, a.gal_einv, mod_at(a.mods, j).q);
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JC; jj++) {
+        const int j = j0 + jj;
+        if (j < a.L) {
+            const ModDev mj = mod_at(a.mods, j);
+            ac[jj].a = addmod(ac[jj].a, submod(a.ks.half_mod[j], reduce64(r.a, mj), mj.q), mj.q);
+            ac[jj].b = addmod(ac[jj].b, submod(a.ks.half_mod[j], reduce64(r.b, mj), mj.q), mj.q);
+            if (with_c0) {  // k = 0: + q_sp * galois(c0)[j] (the sum is multiplied by q_sp^-1 when it is closed)
+                ac[jj].a = addmod(ac[jj].a, shoup_mul(c0[jj].a, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+                ac[jj].b = addmod(ac[jj].b, shoup_mul(c0[jj].b, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+            }
+            st2(a.accH + (bk * a.L + j) * n + i, ac[jj]);
+        }
+    }
+}
+HD void leaf_round_body(const LeafRoundArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = (gid & ((n >> 1) - 1)) << 1;
+    const size_t bk = gid >> (a.logn - 1);   // (item, k)
+    if (bk >= (size_t)a.B * 2) return;
+    const U2 r = ld2(a.r + bk * n + i);
+    const bool with_c0 = a.gal_einv && !(bk & 1);
+    for (int j0 = 0; j0 < a.L; j0 += 4) leaf_round_limbs<4>(a, bk, i, j0, r, with_c0);
 }
 
 // key-switch mod-down by the special prime with rounding: gid over [B][2][L][N]

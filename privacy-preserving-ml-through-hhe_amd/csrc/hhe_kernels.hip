@@ -442,6 +442,7 @@ template <int LL, int MODE> __global__ void __launch_bounds__(ELT_THREADS) ks_ma
 __global__ void __launch_bounds__(ELT_THREADS) ks_corr_kernel(KsCorrArgs a) { ks_corr_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_finish_kernel(KsFinishArgs a) { ks_finish_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) leaf_sum_kernel(LeafSumArgs a) { leaf_sum_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) leaf_round_kernel(LeafRoundArgs a) { leaf_round_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) add_plain_kernel(AddPlainArgs a) { add_plain_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) encode_scatter_kernel(EncodeArgs a) { encode_scatter_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) diag_kernel(DiagArgs a) { diag_body(a, GID); }
@@ -483,6 +484,7 @@ void k_ks_mac(const KsMacArgs &a, rt_stream s)
 void k_ks_corr(const KsCorrArgs &a, rt_stream s) { LAUNCH1D(ks_corr_kernel, ((size_t)2 * a.K) << a.logn, s, a); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream s) { LAUNCH1D(ks_finish_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s) { LAUNCH1D(leaf_sum_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
+void k_leaf_round(const LeafRoundArgs &a, rt_stream s) { LAUNCH1D(leaf_round_kernel, ((size_t)a.B * 2) << (a.logn - 1), s, a); }
 void k_add_plain(const AddPlainArgs &a, rt_stream s) { LAUNCH1D(add_plain_kernel, (size_t)a.B << a.logn, s, a); }
 void k_encode_scatter(const EncodeArgs &a, rt_stream s)
 {

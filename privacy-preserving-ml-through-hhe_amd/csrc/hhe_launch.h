@@ -52,6 +52,7 @@ void k_ks_mac(const KsMacArgs &a, rt_stream s);
 void k_ks_corr(const KsCorrArgs &a, rt_stream s);
 void k_ks_finish(const KsFinishArgs &a, rt_stream s);
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s);
+void k_leaf_round(const LeafRoundArgs &a, rt_stream s);
 void k_add_plain(const AddPlainArgs &a, rt_stream s);
 void k_encode_scatter(const EncodeArgs &a, rt_stream s);
 void k_diag(const DiagArgs &a, rt_stream s);

@@ -226,6 +226,7 @@ void k_ks_mac(const KsMacArgs &a, rt_stream)
 void k_ks_corr(const KsCorrArgs &a, rt_stream) { LOOP(((size_t)2 * a.K) << a.logn, ks_corr_body(a, (size_t)g)); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, ks_finish_body(a, (size_t)g)); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, leaf_sum_body(a, (size_t)g)); }
+void k_leaf_round(const LeafRoundArgs &a, rt_stream) { LOOP(((size_t)a.B * 2) << (a.logn - 1), leaf_round_body(a, (size_t)g)); }
 void k_add_plain(const AddPlainArgs &a, rt_stream) { LOOP((size_t)a.B << a.logn, add_plain_body(a, (size_t)g)); }
 void k_encode_scatter(const EncodeArgs &a, rt_stream) { LOOP((size_t)a.B * a.count * (a.second_off >= 0 ? 2 : 1), encode_scatter_body(a, (size_t)g)); }
 void k_diag(const DiagArgs &a, rt_stream) { LOOP((size_t)(PASTA_R + 1) * PASTA_T * 2 * PASTA_T, diag_body(a, (size_t)g)); }
