@@ -999,19 +999,21 @@ struct NafNode {
 struct FcLeafAcc {  // sums over the leaves of the trie (DESIGN.md "FC rotation trie"): accS in the NTT domain, accH in the
     u64 *accS, *accH, *rscr;  // coefficient domain (rounding terms + q_sp * galois(c0), added by leaf_round_kernel)
 };
-// rounding terms of one leaf key switch: inverse transform of the special limb (r = INTT(S_k[special]) + half) into acc.rscr, then the
-// element-wise sums half_j - (r mod q_j) (+ q_sp * galois(c0) for k = 0) into acc.accH
-static void fc_leaf_round(hhe_ctx *c, const u64 *S, const u64 *parent, u32 einv, const FcLeafAcc &acc, size_t B)
+// rounding terms of m leaf key switches of one parent: inverse transform of their special-limb sums (slots 0..m-1 of S[b][k][.] when
+// m_slots, else the special slot of one leaf) into acc.rscr [B][2][m][N] (r = INTT(S_k[special]) + half), then the element-wise sums
+// half_j - (r mod q_j) (+ q_sp * galois(c0) for k = 0) into acc.accH
+static void fc_leaf_round(hhe_ctx *c, const u64 *S, bool m_slots, const u64 *parent, const u32 *einv, int m, const FcLeafAcc &acc, size_t B)
 {
     const int L = c->L, K = c->K;
     const size_t n = c->n, ln = (size_t)L * n;
-    NttArgs r = ntt_args(c, S + (size_t)(K - 1) * n, acc.rscr, B * 2, K - 1, 1);
-    r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RSP;
+    NttArgs r = ntt_args(c, m_slots ? S : S + (size_t)(K - 1) * n, acc.rscr, B * 2 * m, K - 1, 1);
+    r.src_item_polys = m; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RSP;
     k_ntt(r, true, c->w->stream);
     LeafRoundArgs lr;
     memset(&lr, 0, sizeof(lr));
     lr.r = acc.rscr; lr.accH = acc.accH; lr.base = parent; lr.base_stride = 2 * ln; lr.mods = c->d_mods; lr.logn = c->logn;
-    lr.B = (int)B; lr.L = L; lr.gal_einv = einv; lr.ks = c->ksc;
+    lr.B = (int)B; lr.L = L; lr.m = m; lr.ks = c->ksc;
+    for (int l = 0; l < m; l++) lr.gal_einv[l] = einv[l];
     k_leaf_round(lr, c->w->stream);
 }
 // A leaf's ciphertext is only ever added into the result.  Key switching is linear up to the rounding term, so for
@@ -1039,7 +1041,8 @@ int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t
     m.T = c->w->ws_T; m.key = it->second; m.S = c->w->ws_S; m.s_acc = acc.accS; m.mods = c->d_mods; m.logn = c->logn;
     m.B = (int)B; m.L = L; m.K = K;
     k_ks_mac(m, c->w->stream);
-    fc_leaf_round(c, c->w->ws_S, parent, (u32)nt_invmod(elt, 2 * n), acc, B);
+    const u32 einv = (u32)nt_invmod(elt, 2 * n);
+    fc_leaf_round(c, c->w->ws_S, false, parent, &einv, 1, acc, B);
     return HHE_OK;
 }
 // ---- shared digits (DESIGN.md "FC rotation trie", step 3) ----
@@ -1110,7 +1113,7 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
     else m.S_sp = Usp;
     k_ks_mac(m, c->w->stream);
     if (leaf) {
-        fc_leaf_round(c, c->w->ws_S, parent, einv, *leaf, B);
+        fc_leaf_round(c, c->w->ws_S, false, parent, &einv, 1, *leaf, B);
         return HHE_OK;
     }
     // all 2K sums are inverse-transformed; the mod-down rides in the store of the data limbs' last pass (STORE_KSF)
@@ -1120,6 +1123,27 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
     k_ntt(ad, true, c->w->stream);
     return HHE_OK;
 }
+// m leaf children of one node in one set of launches: one inner-product kernel (the data-limb sums of all of them meet accS once), one
+// inverse transform of their m x 2 special-limb sums, one rounding kernel (accH read and written once)
+int fc_leaves_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, const u32 *elts, int m, const FcLeafAcc &acc, size_t B)
+{
+    const int L = c->L, K = c->K;
+    KsMacLeavesArgs a;
+    memset(&a, 0, sizeof(a));
+    u32 einv[HHE_LEAF_GROUP];
+    for (int l = 0; l < m; l++) {
+        auto it = c->gks->gk.find(elts[l]);
+        if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+        int rc = fc_corr(c, elts[l], it->second, &a.corr[l]);
+        if (rc) return rc;
+        a.key[l] = it->second; a.perm_elt[l] = elts[l];
+        einv[l] = (u32)nt_invmod(elts[l], 2 * c->n);
+    }
+    a.T = tp; a.S = c->w->ws_S; a.s_acc = acc.accS; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K; a.m = m;
+    if (k_ks_mac_leaves(a, c->w->stream)) return fail(HHE_ERR_INVALID, "fc: leaf group");
+    fc_leaf_round(c, c->w->ws_S, true, parent, einv, m, acc, B);
+    return HHE_OK;
+}
 int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out,
                   const FcLeafAcc *acc, size_t B)
 {
@@ -1127,17 +1151,30 @@ int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int de
     const size_t ctw = c->ct_words();
     u64 *tp = c->w->ws_tp + (size_t)(depth - 1) * B * c->L * c->K * c->n;
     fc_parent_digits(c, parent, tp, B);
+    // leaf children first, in groups (the order of the additions into the sums is immaterial: exact modular arithmetic)
+    const int group = c->L <= 4 ? std::min(std::min(HHE_LEAF_GROUP, c->L), c->fc_leaf_group) : 1;
+    u32 elts[HHE_LEAF_GROUP];
+    int m = 0;
+    auto flush = [&]() -> int {
+        int rc = HHE_OK;
+        if (m == 1 || (m > 0 && group == 1)) rc = fc_child_shared(c, parent, tp, elts[0], acc, nullptr, B);
+        else if (m > 1) rc = fc_leaves_shared(c, parent, tp, elts, m, *acc, B);
+        m = 0;
+        return rc;
+    };
     for (int kid : trie[node].kids) {
+        if (!(acc && trie[kid].kids.empty() && trie[kid].mult == 1)) continue;
+        elts[m++] = galois_elt_from_step(c, trie[kid].term);
+        if (m == group) { int rc = flush(); if (rc) return rc; }
+    }
+    { int rc = flush(); if (rc) return rc; }
+    for (int kid : trie[node].kids) {
+        if (acc && trie[kid].kids.empty() && trie[kid].mult == 1) continue;
         const u32 elt = galois_elt_from_step(c, trie[kid].term);
-        if (acc && trie[kid].kids.empty() && trie[kid].mult == 1) {
-            int rc = fc_child_shared(c, parent, tp, elt, acc, nullptr, B);
-            if (rc) return rc;
-            continue;
-        }
         u64 *cur = bufs + (size_t)depth * B * ctw;
         int rc = fc_child_shared(c, parent, tp, elt, nullptr, cur, B);
         if (rc) return rc;
-        for (int m = 0; m < trie[kid].mult; ++m) op_add(c, out, cur, out, B, 2);
+        for (int mm = 0; mm < trie[kid].mult; ++mm) op_add(c, out, cur, out, B, 2);
         if ((rc = fc_dfs_shared(c, trie, kid, depth + 1, cur, bufs, out, acc, B))) return rc;
     }
     return HHE_OK;

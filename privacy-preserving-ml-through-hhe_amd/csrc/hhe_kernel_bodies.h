@@ -919,32 +919,37 @@ HD void leaf_sum_body(const LeafSumArgs &a, size_t gid)
 // the special limb's last inverse pass until round 3: there every limb's read-modify-write sat behind the previous limb's store in the
 // wave's in-order memory counter, 24 dependent round trips per lane and 355 us per launch at 2.2 TB/s.
 template <int JC>
-HD void leaf_round_limbs(const LeafRoundArgs &a, size_t bk, size_t i, int j0, const U2 r, bool with_c0)
+HD void leaf_round_limbs(const LeafRoundArgs &a, size_t bk, size_t i, int j0, bool with_c0)
 {
     const size_t n = (size_t)1 << a.logn;
-    U2 ac[JC], c0[JC];
+    U2 ac[JC];
 #pragma unroll
-    for (int jj = 0; jj < JC; jj++) {
-        const int j = j0 + jj;
-        if (j < a.L) {
-            ac[jj] = ld2(a.accH + (bk * a.L + j) * n + i);
-            if (with_c0) c0[jj] = ld2_galois(a.base + (bk >> 1) * a.base_stride + (size_t)j * n, (u32)i, a.logn, a.gal_einv, mod_at(a.mods, j).q);
-        }
-    }
+    for (int jj = 0; jj < JC; jj++)
+        if (j0 + jj < a.L) ac[jj] = ld2(a.accH + (bk * a.L + j0 + jj) * n + i);
+    for (int l = 0; l < a.m; l++) {
+        const U2 r = ld2(a.r + (bk * a.m + l) * n + i);
+        U2 c0[JC];
 #pragma unroll
-    for (int jj = 0; jj < JC; jj++) {
-        const int j = j0 + jj;
-        if (j < a.L) {
-            const ModDev mj = mod_at(a.mods, j);
-            ac[jj].a = addmod(ac[jj].a, submod(a.ks.half_mod[j], reduce64(r.a, mj), mj.q), mj.q);
-            ac[jj].b = addmod(ac[jj].b, submod(a.ks.half_mod[j], reduce64(r.b, mj), mj.q), mj.q);
-            if (with_c0) {  // k = 0: + q_sp * galois(c0)[j] (the sum is multiplied by q_sp^-1 when it is closed)
-                ac[jj].a = addmod(ac[jj].a, shoup_mul(c0[jj].a, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
-                ac[jj].b = addmod(ac[jj].b, shoup_mul(c0[jj].b, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+        for (int jj = 0; jj < JC; jj++)
+            if (with_c0 && j0 + jj < a.L)
+                c0[jj] = ld2_galois(a.base + (bk >> 1) * a.base_stride + (size_t)(j0 + jj) * n, (u32)i, a.logn, a.gal_einv[l], mod_at(a.mods, j0 + jj).q);
+#pragma unroll
+        for (int jj = 0; jj < JC; jj++) {
+            const int j = j0 + jj;
+            if (j < a.L) {
+                const ModDev mj = mod_at(a.mods, j);
+                ac[jj].a = addmod(ac[jj].a, submod(a.ks.half_mod[j], reduce64(r.a, mj), mj.q), mj.q);
+                ac[jj].b = addmod(ac[jj].b, submod(a.ks.half_mod[j], reduce64(r.b, mj), mj.q), mj.q);
+                if (with_c0) {  // k = 0: + q_sp * galois(c0)[j] (the sum is multiplied by q_sp^-1 when it is closed)
+                    ac[jj].a = addmod(ac[jj].a, shoup_mul(c0[jj].a, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+                    ac[jj].b = addmod(ac[jj].b, shoup_mul(c0[jj].b, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+                }
             }
-            st2(a.accH + (bk * a.L + j) * n + i, ac[jj]);
         }
     }
+#pragma unroll
+    for (int jj = 0; jj < JC; jj++)
+        if (j0 + jj < a.L) st2(a.accH + (bk * a.L + j0 + jj) * n + i, ac[jj]);
 }
 HD void leaf_round_body(const LeafRoundArgs &a, size_t gid)
 {
@@ -952,9 +957,54 @@ HD void leaf_round_body(const LeafRoundArgs &a, size_t gid)
     const size_t i = (gid & ((n >> 1) - 1)) << 1;
     const size_t bk = gid >> (a.logn - 1);   // (item, k)
     if (bk >= (size_t)a.B * 2) return;
-    const U2 r = ld2(a.r + bk * n + i);
-    const bool with_c0 = a.gal_einv && !(bk & 1);
-    for (int j0 = 0; j0 < a.L; j0 += 4) leaf_round_limbs<4>(a, bk, i, j0, r, with_c0);
+    const bool with_c0 = !(bk & 1);
+    for (int j0 = 0; j0 < a.L; j0 += 4) leaf_round_limbs<4>(a, bk, i, j0, with_c0);
+}
+
+// gid over [B][K][N/2] (as ks_mac_body_t): the inner products of m leaf children of one node, see KsMacLeavesArgs
+template <int LL> HD void ks_mac_leaves_body(const KsMacLeavesArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = (gid & ((n >> 1) - 1)) << 1;
+    const size_t bj = gid >> (a.logn - 1);
+    const int J = (int)(bj % a.K);
+    const size_t b = bj / a.K;
+    if (b >= (size_t)a.B) return;
+    ModDev m;
+    m.q = mod_at_u(a.mods, J).q; m.r_lo = mod_at_u(a.mods, J).r_lo; m.r_hi = mod_at_u(a.mods, J).r_hi;
+    const bool data = J < LL;
+    u64 *q0 = a.s_acc + ((b * 2 + 0) * LL + J) * n + i, *q1 = a.s_acc + ((b * 2 + 1) * LL + J) * n + i;
+    U2 c0 = {0, 0}, c1 = {0, 0};
+    if (data) { c0 = ld2(q0); c1 = ld2(q1); }
+    for (int l = 0; l < a.m; l++) {
+        const u32 p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt[l]);
+        const u64 *key = a.key[l], *corr = a.corr[l];
+        U2 t[LL], k0[LL], k1[LL];
+#pragma unroll
+        for (int I = 0; I < LL; I++) {
+            t[I] = ld2(a.T + ((b * LL + I) * a.K + J) * n + (size_t)(p0 & ~1u));   // re-read by the other leaves of the group: cached
+            k0[I] = ld2(key + (((size_t)I * 2 + 0) * a.K + J) * n + i);
+            k1[I] = ld2(key + (((size_t)I * 2 + 1) * a.K + J) * n + i);
+        }
+        const U2 e0 = ld2(corr + ((size_t)0 * a.K + J) * n + i), e1 = ld2(corr + ((size_t)1 * a.K + J) * n + i);
+        Acc128 s0[2] = {{e0.a, 0}, {e0.b, 0}}, s1[2] = {{e1.a, 0}, {e1.b, 0}};
+#pragma unroll
+        for (int I = 0; I < LL; I++) {
+            if (p0 & 1) t[I] = U2{t[I].b, t[I].a};
+            acc_mac(s0[0], t[I].a, k0[I].a); acc_mac(s0[1], t[I].b, k0[I].b);
+            acc_mac(s1[0], t[I].a, k1[I].a); acc_mac(s1[1], t[I].b, k1[I].b);
+        }
+        const U2 r0 = {barrett128(s0[0].lo, s0[0].hi, m), barrett128(s0[1].lo, s0[1].hi, m)};
+        const U2 r1 = {barrett128(s1[0].lo, s1[0].hi, m), barrett128(s1[1].lo, s1[1].hi, m)};
+        if (data) {
+            c0.a = addmod(c0.a, r0.a, m.q); c0.b = addmod(c0.b, r0.b, m.q);
+            c1.a = addmod(c1.a, r1.a, m.q); c1.b = addmod(c1.b, r1.b, m.q);
+        } else {
+            st2_stream<4>(a.S + ((b * 2 + 0) * a.K + l) * n + i, r0);
+            st2_stream<4>(a.S + ((b * 2 + 1) * a.K + l) * n + i, r1);
+        }
+    }
+    if (data) { st2(q0, c0); st2(q1, c1); }
 }
 
 // key-switch mod-down by the special prime with rounding: gid over [B][2][L][N]

@@ -439,6 +439,7 @@ __global__ void __launch_bounds__(ELT_THREADS) galois_kernel(GaloisArgs a) { gal
 __global__ void __launch_bounds__(ELT_THREADS) perm_kernel(PermArgs a) { perm_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_mac_kernel(KsMacArgs a) { ks_mac_body(a, GID); }
 template <int LL, int MODE> __global__ void __launch_bounds__(ELT_THREADS) ks_mac_t_kernel(KsMacArgs a) { ks_mac_body_t<LL, MODE>(a, GID); }
+template <int LL> __global__ void __launch_bounds__(ELT_THREADS) ks_mac_leaves_kernel(KsMacLeavesArgs a) { ks_mac_leaves_body<LL>(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_corr_kernel(KsCorrArgs a) { ks_corr_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) ks_finish_kernel(KsFinishArgs a) { ks_finish_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) leaf_sum_kernel(LeafSumArgs a) { leaf_sum_body(a, GID); }
@@ -480,6 +481,18 @@ void k_ks_mac(const KsMacArgs &a, rt_stream s)
     case KS_LEAF: launch_ks_mac_t<KS_LEAF>(a, s); break;
     default: LAUNCH1D(ks_mac_kernel, ((size_t)a.B * a.K) << (a.logn - 1), s, a); break;
     }
+}
+int k_ks_mac_leaves(const KsMacLeavesArgs &a, rt_stream s)
+{
+    const size_t total = ((size_t)a.B * a.K) << (a.logn - 1);
+    switch (a.L) {
+    case 1: LAUNCH1D((ks_mac_leaves_kernel<1>), total, s, a); break;
+    case 2: LAUNCH1D((ks_mac_leaves_kernel<2>), total, s, a); break;
+    case 3: LAUNCH1D((ks_mac_leaves_kernel<3>), total, s, a); break;
+    case 4: LAUNCH1D((ks_mac_leaves_kernel<4>), total, s, a); break;
+    default: return -1;
+    }
+    return 0;
 }
 void k_ks_corr(const KsCorrArgs &a, rt_stream s) { LAUNCH1D(ks_corr_kernel, ((size_t)2 * a.K) << a.logn, s, a); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream s) { LAUNCH1D(ks_finish_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }

@@ -53,6 +53,7 @@ void k_ks_corr(const KsCorrArgs &a, rt_stream s);
 void k_ks_finish(const KsFinishArgs &a, rt_stream s);
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s);
 void k_leaf_round(const LeafRoundArgs &a, rt_stream s);
+int k_ks_mac_leaves(const KsMacLeavesArgs &a, rt_stream s);  // -1: L > 4 (the caller takes the per-leaf path)
 void k_add_plain(const AddPlainArgs &a, rt_stream s);
 void k_encode_scatter(const EncodeArgs &a, rt_stream s);
 void k_diag(const DiagArgs &a, rt_stream s);

@@ -223,6 +223,18 @@ void k_ks_mac(const KsMacArgs &a, rt_stream)
     default: LOOP(((size_t)a.B * a.K) << (a.logn - 1), ks_mac_body(a, (size_t)g)); break;
     }
 }
+int k_ks_mac_leaves(const KsMacLeavesArgs &a, rt_stream)
+{
+    const size_t total = ((size_t)a.B * a.K) << (a.logn - 1);
+    switch (a.L) {
+    case 1: LOOP(total, (ks_mac_leaves_body<1>(a, (size_t)g))); break;
+    case 2: LOOP(total, (ks_mac_leaves_body<2>(a, (size_t)g))); break;
+    case 3: LOOP(total, (ks_mac_leaves_body<3>(a, (size_t)g))); break;
+    case 4: LOOP(total, (ks_mac_leaves_body<4>(a, (size_t)g))); break;
+    default: return -1;
+    }
+    return 0;
+}
 void k_ks_corr(const KsCorrArgs &a, rt_stream) { LOOP(((size_t)2 * a.K) << a.logn, ks_corr_body(a, (size_t)g)); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, ks_finish_body(a, (size_t)g)); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, leaf_sum_body(a, (size_t)g)); }

@@ -225,8 +225,11 @@ def check_fc_variants(make_ctx, S, orc, mem, monkeypatch, n_in=37):
     vi = np.stack([O.encrypt(S.pk, O.encode(v), 41 + b) for b in range(B)])
     refs = [O.fc_row(vi[b], wc, S.rk, S.gk, n_in)[0] for b in range(B)]
     # (shared digits, leaf sums, items per chunk): chunk 1 -> three chunks round-robin over the internal streams
-    for shared, leafsum, chunk in (("1", "1", "40"), ("0", "1", "40"), ("2", "1", "40"), ("1", "0", "40"), ("0", "0", "40"),
-                                   ("1", "1", "1"), ("2", "1", "1"), ("0", "1", "2")):
+    # fourth column: leaf children of one trie node per launch (default 4, bounded by L; 1 = one leaf at a time)
+    for shared, leafsum, chunk, group in (("1", "1", "40", "4"), ("0", "1", "40", "4"), ("2", "1", "40", "4"), ("1", "0", "40", "4"),
+                                          ("0", "0", "40", "4"), ("1", "1", "1", "4"), ("2", "1", "1", "4"), ("0", "1", "2", "4"),
+                                          ("1", "1", "40", "1"), ("1", "1", "2", "2")):
+        monkeypatch.setenv("HHE_FC_LEAFGROUP", group)
         monkeypatch.setenv("HHE_FC_SHARED", shared)
         monkeypatch.setenv("HHE_FC_LEAFSUM", leafsum)
         monkeypatch.setenv("HHE_FC_CHUNK", chunk)
@@ -236,7 +239,7 @@ def check_fc_variants(make_ctx, S, orc, mem, monkeypatch, n_in=37):
         X.fc_row(mem.to_dev(vi), mem.to_dev(wc[None]), 1, n_in, out, B, relin_slot=0, default_galois_only=False)
         got = mem.to_host(out)
         for b in range(B):
-            assert (got[b] == refs[b]).all(), (shared, leafsum, b)
+            assert (got[b] == refs[b]).all(), (shared, leafsum, chunk, group, b)
         assert X.query("fc_fallbacks") == ((B + int(chunk) - 1) // int(chunk) if shared == "2" else 0)
         X.close()
 
