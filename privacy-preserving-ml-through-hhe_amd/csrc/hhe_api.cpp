@@ -999,21 +999,22 @@ struct NafNode {
 struct FcLeafAcc {  // sums over the leaves of the trie (DESIGN.md "FC rotation trie"): accS in the NTT domain, accH in the
     u64 *accS, *accH, *rscr;  // coefficient domain (rounding terms + q_sp * galois(c0), added by leaf_round_kernel)
 };
-// rounding terms of m leaf key switches of one parent: inverse transform of their special-limb sums (slots 0..m-1 of S[b][k][.] when
-// m_slots, else the special slot of one leaf) into acc.rscr [B][2][m][N] (r = INTT(S_k[special]) + half), then the element-wise sums
-// half_j - (r mod q_j) (+ q_sp * galois(c0) for k = 0) into acc.accH
-static void fc_leaf_round(hhe_ctx *c, const u64 *S, bool m_slots, const u64 *parent, const u32 *einv, int m, const FcLeafAcc &acc, size_t B)
+// rounding terms of m leaf key switches: inverse transform of their special-limb sums (S: [B][2][m][N] when dense, else the special slot
+// of ws_S [B][2][K][N] for one leaf) into acc.rscr [B][2][m][N] (r = INTT(S_k[special]) + half), then the element-wise sums
+// half_j - (r mod q_j) (+ q_sp * galois_l(c0 of leaf l's parent) for k = 0) into acc.accH
+static void fc_leaf_round(hhe_ctx *c, const u64 *S, bool dense, const u64 *const *parents, const u32 *einv, int m, const FcLeafAcc &acc, size_t B)
 {
     const int L = c->L, K = c->K;
     const size_t n = c->n, ln = (size_t)L * n;
-    NttArgs r = ntt_args(c, m_slots ? S : S + (size_t)(K - 1) * n, acc.rscr, B * 2 * m, K - 1, 1);
-    r.src_item_polys = m; r.src_item_stride = (size_t)K * n; r.store_op = STORE_RSP;
+    NttArgs r = ntt_args(c, dense ? S : S + (size_t)(K - 1) * n, acc.rscr, B * 2 * m, K - 1, 1);
+    if (!dense) { r.src_item_polys = 1; r.src_item_stride = (size_t)K * n; }
+    r.store_op = STORE_RSP;
     k_ntt(r, true, c->w->stream);
     LeafRoundArgs lr;
     memset(&lr, 0, sizeof(lr));
-    lr.r = acc.rscr; lr.accH = acc.accH; lr.base = parent; lr.base_stride = 2 * ln; lr.mods = c->d_mods; lr.logn = c->logn;
+    lr.r = acc.rscr; lr.accH = acc.accH; lr.base_stride = 2 * ln; lr.mods = c->d_mods; lr.logn = c->logn;
     lr.B = (int)B; lr.L = L; lr.m = m; lr.ks = c->ksc;
-    for (int l = 0; l < m; l++) lr.gal_einv[l] = einv[l];
+    for (int l = 0; l < m; l++) { lr.base[l] = parents[l]; lr.gal_einv[l] = einv[l]; }
     k_leaf_round(lr, c->w->stream);
 }
 // A leaf's ciphertext is only ever added into the result.  Key switching is linear up to the rounding term, so for
@@ -1042,7 +1043,7 @@ int fc_leaf(hhe_ctx *c, const u64 *parent, u32 elt, const FcLeafAcc &acc, size_t
     m.B = (int)B; m.L = L; m.K = K;
     k_ks_mac(m, c->w->stream);
     const u32 einv = (u32)nt_invmod(elt, 2 * n);
-    fc_leaf_round(c, c->w->ws_S, false, parent, &einv, 1, acc, B);
+    fc_leaf_round(c, c->w->ws_S, false, &parent, &einv, 1, acc, B);
     return HHE_OK;
 }
 // ---- shared digits (DESIGN.md "FC rotation trie", step 3) ----
@@ -1113,7 +1114,7 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
     else m.S_sp = Usp;
     k_ks_mac(m, c->w->stream);
     if (leaf) {
-        fc_leaf_round(c, c->w->ws_S, false, parent, &einv, 1, *leaf, B);
+        fc_leaf_round(c, c->w->ws_S, false, &parent, &einv, 1, *leaf, B);
         return HHE_OK;
     }
     // all 2K sums are inverse-transformed; the mod-down rides in the store of the data limbs' last pass (STORE_KSF)
@@ -1123,61 +1124,115 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
     k_ntt(ad, true, c->w->stream);
     return HHE_OK;
 }
-// m leaf children of one node in one set of launches: one inner-product kernel (the data-limb sums of all of them meet accS once), one
-// inverse transform of their m x 2 special-limb sums, one rounding kernel (accH read and written once)
-int fc_leaves_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, const u32 *elts, int m, const FcLeafAcc &acc, size_t B)
-{
-    const int L = c->L, K = c->K;
-    KsMacLeavesArgs a;
-    memset(&a, 0, sizeof(a));
-    u32 einv[HHE_LEAF_GROUP];
-    for (int l = 0; l < m; l++) {
-        auto it = c->gks->gk.find(elts[l]);
-        if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
-        int rc = fc_corr(c, elts[l], it->second, &a.corr[l]);
-        if (rc) return rc;
-        a.key[l] = it->second; a.perm_elt[l] = elts[l];
-        einv[l] = (u32)nt_invmod(elts[l], 2 * c->n);
-    }
-    a.T = tp; a.S = c->w->ws_S; a.s_acc = acc.accS; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K; a.m = m;
-    if (k_ks_mac_leaves(a, c->w->stream)) return fail(HHE_ERR_INVALID, "fc: leaf group");
-    fc_leaf_round(c, c->w->ws_S, true, parent, einv, m, acc, B);
-    return HHE_OK;
-}
-int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out,
-                  const FcLeafAcc *acc, size_t B)
-{
-    if (trie[node].kids.empty()) return HHE_OK;
-    const size_t ctw = c->ct_words();
-    u64 *tp = c->w->ws_tp + (size_t)(depth - 1) * B * c->L * c->K * c->n;
-    fc_parent_digits(c, parent, tp, B);
-    // leaf children first, in groups (the order of the additions into the sums is immaterial: exact modular arithmetic)
-    const int group = c->L <= 4 ? std::min(std::min(HHE_LEAF_GROUP, c->L), c->fc_leaf_group) : 1;
-    u32 elts[HHE_LEAF_GROUP];
+// The walk over the trie with shared digits.  A node's digit transforms and ciphertext live in a slot of the lane's pool (Lane::FcSlot)
+// for as long as something still reads them: the walk below the node, and its LEAF children, whose key switches are queued and run in
+// groups of up to HHE_LEAF_GROUP -- leaves of different nodes together -- with one inner-product launch (the data-limb sums of all of them
+// meet accS in one read-modify-write), one inverse transform of their 2 x m special-limb sums and one rounding kernel (accH read and
+// written once).  The order of the additions into the sums is immaterial: exact modular arithmetic.
+struct FcWalk {
+    hhe_ctx *c;
+    const std::vector<NafNode> &trie;
+    u64 *out;
+    const FcLeafAcc *acc;
+    size_t B;
+    int group, max_slots;
+    struct Leaf { int slot; const u64 *parent; u32 elt; } q[HHE_LEAF_GROUP];
     int m = 0;
-    auto flush = [&]() -> int {
+
+    int flush()
+    {
+        Lane &ln = *c->w;
         int rc = HHE_OK;
-        if (m == 1 || (m > 0 && group == 1)) rc = fc_child_shared(c, parent, tp, elts[0], acc, nullptr, B);
-        else if (m > 1) rc = fc_leaves_shared(c, parent, tp, elts, m, *acc, B);
+        if (m > 0 && (group == 1 || m == 1)) {
+            for (int l = 0; l < m && !rc; l++) rc = fc_child_shared(c, q[l].parent, ln.fc_slots[q[l].slot].tp, q[l].elt, acc, nullptr, B);
+        } else if (m > 1) {
+            const int L = c->L, K = c->K;
+            KsMacLeavesArgs a;
+            memset(&a, 0, sizeof(a));
+            u32 einv[HHE_LEAF_GROUP];
+            const u64 *parents[HHE_LEAF_GROUP];
+            for (int l = 0; l < m; l++) {
+                auto it = c->gks->gk.find(q[l].elt);
+                if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+                if ((rc = fc_corr(c, q[l].elt, it->second, &a.corr[l]))) return rc;
+                a.T[l] = ln.fc_slots[q[l].slot].tp; a.key[l] = it->second; a.perm_elt[l] = q[l].elt;
+                einv[l] = (u32)nt_invmod(q[l].elt, 2 * c->n);
+                parents[l] = q[l].parent;
+            }
+            a.S_sp = ln.ws_leaf; a.s_acc = acc->accS; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K; a.m = m;
+            if (k_ks_mac_leaves(a, ln.stream)) return fail(HHE_ERR_INVALID, "fc: leaf group");
+            fc_leaf_round(c, ln.ws_leaf, true, parents, einv, m, *acc, B);
+        }
+        for (int l = 0; l < m; l++) ln.fc_slots[q[l].slot].refs--;
         m = 0;
         return rc;
-    };
-    for (int kid : trie[node].kids) {
-        if (!(acc && trie[kid].kids.empty() && trie[kid].mult == 1)) continue;
-        elts[m++] = galois_elt_from_step(c, trie[kid].term);
-        if (m == group) { int rc = flush(); if (rc) return rc; }
     }
-    { int rc = flush(); if (rc) return rc; }
-    for (int kid : trie[node].kids) {
-        if (acc && trie[kid].kids.empty() && trie[kid].mult == 1) continue;
-        const u32 elt = galois_elt_from_step(c, trie[kid].term);
-        u64 *cur = bufs + (size_t)depth * B * ctw;
-        int rc = fc_child_shared(c, parent, tp, elt, nullptr, cur, B);
-        if (rc) return rc;
-        for (int mm = 0; mm < trie[kid].mult; ++mm) op_add(c, out, cur, out, B, 2);
-        if ((rc = fc_dfs_shared(c, trie, kid, depth + 1, cur, bufs, out, acc, B))) return rc;
+    // a free slot (grow-only pool; everything runs in stream order on the lane's stream, so a slot whose readers have been ENQUEUED is free)
+    int acquire(int *slot)
+    {
+        Lane &ln = *c->w;
+        for (int pass = 0; pass < 2; pass++) {
+            for (size_t i = 0; i < ln.fc_slots.size(); i++)
+                if (ln.fc_slots[i].refs == 0) { ln.fc_slots[i].refs = 1; *slot = (int)i; return HHE_OK; }
+            if ((int)ln.fc_slots.size() < max_slots) {
+                Lane::FcSlot sl;
+                sl.tp = (u64 *)rt_malloc(B * (size_t)c->L * c->K * c->n * 8);
+                sl.ct = (u64 *)rt_malloc(B * c->ct_words() * 8);
+                if (!sl.tp || !sl.ct) { rt_free(sl.tp); rt_free(sl.ct); return dev_fail("hhe_fc_row workspace"); }
+                sl.refs = 1;
+                ln.fc_slots.push_back(sl);
+                *slot = (int)ln.fc_slots.size() - 1;
+                return HHE_OK;
+            }
+            int rc = flush();  // the queued leaves hold the remaining slots
+            if (rc) return rc;
+        }
+        return fail(HHE_ERR_INVALID, "hhe_fc_row: slot pool");
     }
-    return HHE_OK;
+    // node's ciphertext is `parent`; `slot` receives the digit transforms of its c1
+    int walk(int node, const u64 *parent, int slot)
+    {
+        if (trie[node].kids.empty()) return HHE_OK;
+        Lane &ln = *c->w;
+        fc_parent_digits(c, parent, ln.fc_slots[slot].tp, B);
+        int rc;
+        for (int kid : trie[node].kids) {
+            if (!(acc && trie[kid].kids.empty() && trie[kid].mult == 1)) continue;
+            q[m].slot = slot; q[m].parent = parent; q[m].elt = galois_elt_from_step(c, trie[kid].term);
+            ++m;
+            ln.fc_slots[slot].refs++;
+            if (m >= group && (rc = flush())) return rc;
+        }
+        for (int kid : trie[node].kids) {
+            if (acc && trie[kid].kids.empty() && trie[kid].mult == 1) continue;
+            const u32 elt = galois_elt_from_step(c, trie[kid].term);
+            int k = -1;
+            if ((rc = acquire(&k))) return rc;
+            u64 *cur = ln.fc_slots[k].ct;
+            if ((rc = fc_child_shared(c, parent, ln.fc_slots[slot].tp, elt, nullptr, cur, B))) return rc;
+            for (int mm = 0; mm < trie[kid].mult; ++mm) op_add(c, out, cur, out, B, 2);
+            if ((rc = walk(kid, cur, k))) return rc;
+            ln.fc_slots[k].refs--;
+        }
+        return HHE_OK;
+    }
+};
+int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int max_depth, const u64 *prod, u64 *out, const FcLeafAcc *acc, size_t B)
+{
+    Lane &ln = *c->w;
+    if (ln.fc_slot_cap < B) {  // slots of a smaller batch: start over
+        rt_sync(ln.stream);
+        for (auto &sl : ln.fc_slots) { rt_free(sl.tp); rt_free(sl.ct); }
+        ln.fc_slots.clear();
+        ln.fc_slot_cap = B;
+    }
+    for (auto &sl : ln.fc_slots) sl.refs = 0;
+    const int group = c->L <= 4 ? std::min(HHE_LEAF_GROUP, c->fc_leaf_group) : 1;  // k_ks_mac_leaves is instantiated for L <= 4
+    FcWalk w{c, trie, out, acc, B, group, max_depth + 1 + group};
+    int root = -1, rc = w.acquire(&root);
+    if (!rc) rc = w.walk(0, prod, root);
+    if (!rc) rc = w.flush();
+    return rc;
 }
 int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out,
            const FcLeafAcc *acc, size_t B)
@@ -1339,11 +1394,19 @@ static int fc_row_chunk(hhe_ctx *c, Lane &lane, bool shared, const uint64_t *vi,
     auto run = [&](bool shared) -> int {
         rt_d2d(out, prod, B * ctw * 8, ln.stream);
         auto dfs = [&](const FcLeafAcc *acc) {
-            return shared ? fc_dfs_shared(c, trie, 0, 1, prod, ln.ws_rot, out, acc, B) : fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, acc, B);
+            return shared ? fc_dfs_shared(c, trie, max_depth, prod, out, acc, B) : fc_dfs(c, trie, 0, 1, prod, ln.ws_rot, out, acc, B);
         };
         if (!c->fc_leaf_sums) return dfs(nullptr);
         FcLeafAcc acc;
-        acc.accS = ln.ws_ct[0]; acc.accH = ln.ws_ct[1]; acc.rscr = ln.ws_ct[2];
+        const size_t leaf_words = B * 2 * (size_t)HHE_LEAF_GROUP * c->n;
+        if (ln.leaf_cap < B) {
+            rt_sync(ln.stream);
+            rt_free(ln.ws_leaf);
+            ln.leaf_cap = 0;
+            if (!(ln.ws_leaf = (u64 *)rt_malloc(2 * leaf_words * 8))) return dev_fail("hhe_fc_row workspace");
+            ln.leaf_cap = B;
+        }
+        acc.accS = ln.ws_ct[0]; acc.accH = ln.ws_ct[1]; acc.rscr = ln.ws_leaf + ln.leaf_cap * 2 * (size_t)HHE_LEAF_GROUP * c->n;
         rt_memset(acc.accS, 0, 2 * bln * 8, ln.stream);
         rt_memset(acc.accH, 0, 2 * bln * 8, ln.stream);
         int r = dfs(&acc);
@@ -1357,13 +1420,5 @@ static int fc_row_chunk(hhe_ctx *c, Lane &lane, bool shared, const uint64_t *vi,
         return HHE_OK;
     };
     if (!shared || max_depth == 0) return run(false);
-    const size_t tp_words = B * (size_t)L * c->K * c->n;
-    if (ln.tp_cap < B || ln.tp_depth < (size_t)max_depth) {
-        rt_sync(ln.stream);
-        rt_free(ln.ws_tp);
-        ln.ws_tp = (u64 *)rt_malloc((size_t)max_depth * tp_words * 8);
-        if (!ln.ws_tp) { ln.tp_cap = ln.tp_depth = 0; return dev_fail("hhe_fc_row workspace"); }
-        ln.tp_cap = B; ln.tp_depth = (size_t)max_depth;
-    }
     return run(true);
 }

@@ -239,26 +239,27 @@ struct LeafSumArgs {  // out[b][k][j] += qsp_inv_j * (accS[b][k][j] (INTT'd) + a
     KsConsts ks;
 };
 
-constexpr int HHE_LEAF_GROUP = 4;  // leaf children of one trie node handled by one launch (also bounded by L: their special-limb sums use the L data slots of S)
-struct LeafRoundArgs {  // accH[b][k][j] += sum over the m leaves of: half_j - (r_l[b][k] mod q_j) (+ q_sp * galois_l(c0_b)[j] for k = 0)
+constexpr int HHE_LEAF_GROUP = 4;  // leaf key switches of the FC trie handled by one launch (leaves of ANY nodes whose digit transforms are still resident);
+                                   // ms per MNIST sample at 1 / 2 / 4 / 8 per launch: 53.3 / 50.6 / 50.3 / 51.6
+struct LeafRoundArgs {  // accH[b][k][j] += sum over the m leaves of: half_j - (r_l[b][k] mod q_j) (+ q_sp * galois_l(c0_b of leaf l's parent)[j] for k = 0)
     const u64 *r;      // [B][2][m][N]: INTT(S_k[special]) + floor(q_sp/2) mod q_sp of leaf l (the STORE_RSP result)
     u64 *accH;         // [B][2][L][N]
-    const u64 *base;   // un-rotated parent ciphertexts (item b at base + b * base_stride, c0 limbs first); read through the Galois maps
+    const u64 *base[HHE_LEAF_GROUP];  // un-rotated parent ciphertexts of leaf l (item b at base[l] + b * base_stride, c0 limbs first); read through the Galois maps
     size_t base_stride;
     const ModDev *mods;
     int logn, B, L, m;
     u32 gal_einv[HHE_LEAF_GROUP];  // elt_l^-1 mod 2N
     KsConsts ks;
 };
-// Key-switch inner products of m leaf children of ONE trie node from the node's shared digit transforms (KsMacArgs with perm_elt / corr,
+// Key-switch inner products of m leaf key switches from the shared digit transforms of their parents (KsMacArgs with perm_elt / corr,
 // once per leaf): the data-limb sums of all m leaves go into s_acc with ONE read-modify-write, the special-limb sums of leaf l into
-// slot l < L of S[b][k][.] (the data slots are free in this mode).  The digit transforms of item b are read m times back to back.
+// S_sp[b][k][l].  Leaves of one parent read the same digit transforms back to back (cached).
 struct KsMacLeavesArgs {
-    const u64 *T;      // [B][L][K][N]
-    u64 *S;            // [B][2][K][N]
+    u64 *S_sp;         // [B][2][m][N]
     u64 *s_acc;        // [B][2][L][N]
     const ModDev *mods;
     int logn, B, L, K, m;
+    const u64 *T[HHE_LEAF_GROUP];     // [B][L][K][N] digit transforms of the un-rotated c1 of leaf l's parent
     const u64 *key[HHE_LEAF_GROUP];   // [L][2][K][N]
     const u64 *corr[HHE_LEAF_GROUP];  // [2][K][N]
     u32 perm_elt[HHE_LEAF_GROUP];

@@ -332,7 +332,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
     if (const char *e = getenv("HHE_BLOCK_CACHE_MB")) c->block_cache_limit = (size_t)std::max(0, atoi(e)) << 20;
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
-    if (const char *e = getenv("HHE_FC_LEAFGROUP")) c->fc_leaf_group = std::max(1, atoi(e));
+    if (const char *e = getenv("HHE_FC_LEAFGROUP")) c->fc_leaf_group = std::max(1, std::min(HHE_LEAF_GROUP, atoi(e)));
     if (const char *e = getenv("HHE_FC_SHARED")) c->fc_shared = atoi(e);
     if (const char *e = getenv("HHE_FC_CHUNK")) c->fc_chunk = (size_t)std::max(0, atoi(e));
     if (const char *e = getenv("HHE_STREAMS")) c->nstreams = std::max(0, std::min(HHE_MAX_STREAMS, atoi(e)));
@@ -360,7 +360,9 @@ static void free_lane(Lane &ln)
     rt_free(ln.ws_T); rt_free(ln.ws_S); rt_free(ln.ws_d); rt_free(ln.ws_ct3); rt_free(ln.ws_plain); rt_free(ln.ws_vals);
     for (auto &p : ln.ws_ct) { rt_free(p); p = nullptr; }
     rt_free(ln.ws_rot); ln.ws_rot = nullptr; ln.rot_cap = 0;
-    rt_free(ln.ws_tp); ln.ws_tp = nullptr; ln.tp_cap = ln.tp_depth = 0;
+    for (auto &sl : ln.fc_slots) { rt_free(sl.tp); rt_free(sl.ct); }
+    ln.fc_slots.clear(); ln.fc_slot_cap = 0;
+    rt_free(ln.ws_leaf); ln.ws_leaf = nullptr; ln.leaf_cap = 0;
     rt_free((void *)ln.d_ptrs); ln.d_ptrs = nullptr; ln.ptr_cap = 0;
     for (auto &pr : ln.prof_ev) { rt_event_destroy(pr.first); rt_event_destroy(pr.second); }
     ln.prof_ev.clear(); ln.prof_used = 0;

@@ -50,8 +50,13 @@ struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `c
     size_t ptr_cap = 0;
     u64 *ws_rot = nullptr;   // [B][16][2][L][N] babystep rotations (allocated on first BSGS use)
     size_t rot_cap = 0;
-    u64 *ws_tp = nullptr;    // FC shared digits: [depth][B][L][K][N] digit transforms of the un-rotated c1 of each trie level
-    size_t tp_cap = 0, tp_depth = 0;
+    // FC shared digits: one slot per trie node that is still needed -- the digit transforms of its un-rotated c1 (tp [B][L][K][N]) and its
+    // ciphertext (ct [B][2][L][N]); refs = 1 while the depth-first walk is below the node + 1 per queued leaf key switch that reads it
+    struct FcSlot { u64 *tp = nullptr, *ct = nullptr; int refs = 0; };
+    std::vector<FcSlot> fc_slots;
+    size_t fc_slot_cap = 0;  // items the slots were sized for
+    u64 *ws_leaf = nullptr;  // FC leaf groups: special-limb sums [B][2][G][N] | their inverse transforms [B][2][G][N], G = HHE_LEAF_GROUP
+    size_t leaf_cap = 0;
     u32 *zero_flag = nullptr; // device flag of the chunk this lane is evaluating (shared-digit FC)
     // host staging of small per-call inputs (mask values, pointer tables): it outlives the asynchronous copy, and the next
     // user waits for that copy (ev_stage) before overwriting it
@@ -83,7 +88,7 @@ struct hhe_ctx {
     std::vector<int> pm_ok;        // per ModDev index: the modulus has the pseudo-Mersenne form the lazy butterflies fold with (ModDev::pm_ok)
     u64 fc_fallbacks = 0;          // how often the shared-digit path had to be recomputed exactly
     int fc_shared = 1;             // FC rotation trie: children of a node share the digit transforms of its c1 (HHE_FC_SHARED; 2 = force the fallback, tests)
-    int fc_leaf_group = 4;         // FC rotation trie: leaf children of a node per launch (HHE_FC_LEAFGROUP; 1 = one leaf at a time)
+    int fc_leaf_group = HHE_LEAF_GROUP;  // FC rotation trie: leaf key switches per launch, across the nodes whose digits are resident (HHE_FC_LEAFGROUP; 1 = one leaf at a time)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
     size_t fc_chunk = 160;         // items per internal chunk of hhe_fc_row (0 = whole batch); ms per MNIST sample (784x10, 16 samples): 64: 60.5, 80: 60.6, 96: 60.6, 128: 59.5, 160: 58.4
                                    // (round 1: 40: 67.1, 80: 64.9, 160: 64.0); the trie's small launches (2 polynomials per item) want more than one round of workgroups

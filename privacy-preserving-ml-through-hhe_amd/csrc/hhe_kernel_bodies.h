@@ -932,7 +932,7 @@ HD void leaf_round_limbs(const LeafRoundArgs &a, size_t bk, size_t i, int j0, bo
 #pragma unroll
         for (int jj = 0; jj < JC; jj++)
             if (with_c0 && j0 + jj < a.L)
-                c0[jj] = ld2_galois(a.base + (bk >> 1) * a.base_stride + (size_t)(j0 + jj) * n, (u32)i, a.logn, a.gal_einv[l], mod_at(a.mods, j0 + jj).q);
+                c0[jj] = ld2_galois(a.base[l] + (bk >> 1) * a.base_stride + (size_t)(j0 + jj) * n, (u32)i, a.logn, a.gal_einv[l], mod_at(a.mods, j0 + jj).q);
 #pragma unroll
         for (int jj = 0; jj < JC; jj++) {
             const int j = j0 + jj;
@@ -978,11 +978,11 @@ template <int LL> HD void ks_mac_leaves_body(const KsMacLeavesArgs &a, size_t gi
     if (data) { c0 = ld2(q0); c1 = ld2(q1); }
     for (int l = 0; l < a.m; l++) {
         const u32 p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt[l]);
-        const u64 *key = a.key[l], *corr = a.corr[l];
+        const u64 *key = a.key[l], *corr = a.corr[l], *T = a.T[l];
         U2 t[LL], k0[LL], k1[LL];
 #pragma unroll
         for (int I = 0; I < LL; I++) {
-            t[I] = ld2(a.T + ((b * LL + I) * a.K + J) * n + (size_t)(p0 & ~1u));   // re-read by the other leaves of the group: cached
+            t[I] = ld2(T + ((b * LL + I) * a.K + J) * n + (size_t)(p0 & ~1u));   // leaves of one parent re-read the same words: cached
             k0[I] = ld2(key + (((size_t)I * 2 + 0) * a.K + J) * n + i);
             k1[I] = ld2(key + (((size_t)I * 2 + 1) * a.K + J) * n + i);
         }
@@ -1000,8 +1000,8 @@ template <int LL> HD void ks_mac_leaves_body(const KsMacLeavesArgs &a, size_t gi
             c0.a = addmod(c0.a, r0.a, m.q); c0.b = addmod(c0.b, r0.b, m.q);
             c1.a = addmod(c1.a, r1.a, m.q); c1.b = addmod(c1.b, r1.b, m.q);
         } else {
-            st2_stream<4>(a.S + ((b * 2 + 0) * a.K + l) * n + i, r0);
-            st2_stream<4>(a.S + ((b * 2 + 1) * a.K + l) * n + i, r1);
+            st2_stream<4>(a.S_sp + ((b * 2 + 0) * a.m + l) * n + i, r0);
+            st2_stream<4>(a.S_sp + ((b * 2 + 1) * a.m + l) * n + i, r1);
         }
     }
     if (data) { st2(q0, c0); st2(q1, c1); }

@@ -225,10 +225,10 @@ def check_fc_variants(make_ctx, S, orc, mem, monkeypatch, n_in=37):
     vi = np.stack([O.encrypt(S.pk, O.encode(v), 41 + b) for b in range(B)])
     refs = [O.fc_row(vi[b], wc, S.rk, S.gk, n_in)[0] for b in range(B)]
     # (shared digits, leaf sums, items per chunk): chunk 1 -> three chunks round-robin over the internal streams
-    # fourth column: leaf children of one trie node per launch (default 4, bounded by L; 1 = one leaf at a time)
+    # fourth column: leaf key switches per launch (leaves of any nodes whose digit transforms are resident; 1 = one leaf at a time)
     for shared, leafsum, chunk, group in (("1", "1", "40", "4"), ("0", "1", "40", "4"), ("2", "1", "40", "4"), ("1", "0", "40", "4"),
                                           ("0", "0", "40", "4"), ("1", "1", "1", "4"), ("2", "1", "1", "4"), ("0", "1", "2", "4"),
-                                          ("1", "1", "40", "1"), ("1", "1", "2", "2")):
+                                          ("1", "1", "40", "1"), ("1", "1", "2", "2"), ("1", "1", "40", "3")):
         monkeypatch.setenv("HHE_FC_LEAFGROUP", group)
         monkeypatch.setenv("HHE_FC_SHARED", shared)
         monkeypatch.setenv("HHE_FC_LEAFSUM", leafsum)
