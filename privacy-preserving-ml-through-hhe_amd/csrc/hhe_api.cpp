@@ -1095,7 +1095,7 @@ void fc_parent_digits(hhe_ctx *c, const u64 *parent, u64 *tp, size_t B)
     k_ntt(a, false, c->w->stream);
 }
 // one child of a node from the node's shared digit transforms: leaf (sums only) or full ciphertext into `cur`
-int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const FcLeafAcc *leaf, u64 *cur, size_t B)
+int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const FcLeafAcc *leaf, u64 *cur, size_t B, u64 *add_to = nullptr)
 {
     auto it = c->gks->gk.find(elt);
     if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
@@ -1117,11 +1117,14 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
         fc_leaf_round(c, c->w->ws_S, false, &parent, &einv, 1, *leaf, B);
         return HHE_OK;
     }
-    // all 2K sums are inverse-transformed; the mod-down rides in the store of the data limbs' last pass (STORE_KSF)
-    op_ntt(c, Usp, B * 2, K - 1, 1, true, STORE_RSP);
+    // all 2K sums are inverse-transformed (the row passes of the special and the data limbs in one grid); the mod-down rides in the
+    // store of the data limbs' last pass (STORE_KSF), and so does the addition of a child that is itself a term of the sum (add_to)
+    NttArgs as = ntt_args(c, Usp, Usp, B * 2, K - 1, 1);
+    as.store_op = STORE_RSP;
     NttArgs ad = ntt_args(c, c->w->ws_S, c->w->ws_S, B * 2 * L, 0, L);
     ad.store_op = STORE_KSF; ad.aux_r = Usp; ad.aux_in = parent; ad.base_stride = 2 * ln; ad.base_mask = 1; ad.gal_einv = einv; ad.aux_out = cur;
-    k_ntt(ad, true, c->w->stream);
+    ad.acc = add_to;
+    k_ntt2_inv(as, ad, c->w->stream);
     return HHE_OK;
 }
 // The walk over the trie with shared digits.  A node's digit transforms and ciphertext live in a slot of the lane's pool (Lane::FcSlot)
@@ -1209,8 +1212,9 @@ struct FcWalk {
             int k = -1;
             if ((rc = acquire(&k))) return rc;
             u64 *cur = ln.fc_slots[k].ct;
-            if ((rc = fc_child_shared(c, parent, ln.fc_slots[slot].tp, elt, nullptr, cur, B))) return rc;
-            for (int mm = 0; mm < trie[kid].mult; ++mm) op_add(c, out, cur, out, B, 2);
+            // a child that is itself a term of the sum (distinct steps have distinct term sequences: mult is 0 or 1) is added in its own epilogue
+            if ((rc = fc_child_shared(c, parent, ln.fc_slots[slot].tp, elt, nullptr, cur, B, trie[kid].mult ? out : nullptr))) return rc;
+            for (int mm = 1; mm < trie[kid].mult; ++mm) op_add(c, out, cur, out, B, 2);
             if ((rc = walk(kid, cur, k))) return rc;
             ln.fc_slots[k].refs--;
         }

@@ -357,6 +357,7 @@ HD StorePre ntt_store_fetch(const NttArgs &a, const NttGeom &g, size_t pbase, in
                 const u64 *bp = a.aux_in + (bk >> 1) * a.base_stride + ((bk & 1) * a.L + g.poly % a.L) * g.n;
                 p.d = a.gal_einv ? ld2_galois(bp, (u32)gi, a.logn, a.gal_einv, mod_at(a.mods, a.mod_base + g.poly % a.mod_cycle).q) : ld2(bp + gi);
             }
+            if (a.acc) p.acc = ld2(a.acc + pbase + gi);
         }
     } else if (a.store_op == STORE_MUL || a.store_op == STORE_MAC) {
         const gptr mp = as_global(a.mul_ptrs ? a.mul_ptrs[g.poly / a.mul_item_polys] : a.mul);
@@ -399,6 +400,7 @@ HD void ntt_store_pair(const NttArgs &a, const NttGeom &g, const ModDev &m, u64 
                 o[k] = base ? addmod(t, bb[k], q) : t;
             }
             st2(a.aux_out + pbase + gi, U2{o[0], o[1]});
+            if (a.acc) st2(a.acc + pbase + gi, U2{addmod(pre.acc.a, o[0], q), addmod(pre.acc.b, o[1], q)});  // acc [B][2][L][N] += the finished ciphertext
             return;
         }
         else if (a.store_op == STORE_KS1) {
@@ -918,31 +920,36 @@ HD void leaf_sum_body(const LeafSumArgs &a, size_t gid)
 // Every load of a lane (r, the L sums, the L Galois-mapped c0 words) is requested before its first store.  This was the epilogue of
 // the special limb's last inverse pass until round 3: there every limb's read-modify-write sat behind the previous limb's store in the
 // wave's in-order memory counter, 24 dependent round trips per lane and 355 us per launch at 2.2 TB/s.
-template <int JC>
+// M = leaves of the launch as a compile-time constant: the loads of ALL leaves (r and the Galois-mapped c0 words, 8 bytes each from a
+// different cache line) are in flight before the first of them is used
+template <int JC, int M>
 HD void leaf_round_limbs(const LeafRoundArgs &a, size_t bk, size_t i, int j0, bool with_c0)
 {
     const size_t n = (size_t)1 << a.logn;
-    U2 ac[JC];
+    U2 ac[JC], r[M], c0[M][JC];
 #pragma unroll
     for (int jj = 0; jj < JC; jj++)
         if (j0 + jj < a.L) ac[jj] = ld2(a.accH + (bk * a.L + j0 + jj) * n + i);
-    for (int l = 0; l < a.m; l++) {
-        const U2 r = ld2(a.r + (bk * a.m + l) * n + i);
-        U2 c0[JC];
+#pragma unroll
+    for (int l = 0; l < M; l++) {
+        r[l] = ld2(a.r + (bk * M + l) * n + i);
 #pragma unroll
         for (int jj = 0; jj < JC; jj++)
             if (with_c0 && j0 + jj < a.L)
-                c0[jj] = ld2_galois(a.base[l] + (bk >> 1) * a.base_stride + (size_t)(j0 + jj) * n, (u32)i, a.logn, a.gal_einv[l], mod_at(a.mods, j0 + jj).q);
+                c0[l][jj] = ld2_galois(a.base[l] + (bk >> 1) * a.base_stride + (size_t)(j0 + jj) * n, (u32)i, a.logn, a.gal_einv[l], mod_at(a.mods, j0 + jj).q);
+    }
+#pragma unroll
+    for (int l = 0; l < M; l++) {
 #pragma unroll
         for (int jj = 0; jj < JC; jj++) {
             const int j = j0 + jj;
             if (j < a.L) {
                 const ModDev mj = mod_at(a.mods, j);
-                ac[jj].a = addmod(ac[jj].a, submod(a.ks.half_mod[j], reduce64(r.a, mj), mj.q), mj.q);
-                ac[jj].b = addmod(ac[jj].b, submod(a.ks.half_mod[j], reduce64(r.b, mj), mj.q), mj.q);
+                ac[jj].a = addmod(ac[jj].a, submod(a.ks.half_mod[j], reduce64(r[l].a, mj), mj.q), mj.q);
+                ac[jj].b = addmod(ac[jj].b, submod(a.ks.half_mod[j], reduce64(r[l].b, mj), mj.q), mj.q);
                 if (with_c0) {  // k = 0: + q_sp * galois(c0)[j] (the sum is multiplied by q_sp^-1 when it is closed)
-                    ac[jj].a = addmod(ac[jj].a, shoup_mul(c0[jj].a, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
-                    ac[jj].b = addmod(ac[jj].b, shoup_mul(c0[jj].b, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+                    ac[jj].a = addmod(ac[jj].a, shoup_mul(c0[l][jj].a, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
+                    ac[jj].b = addmod(ac[jj].b, shoup_mul(c0[l][jj].b, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
                 }
             }
         }
@@ -951,14 +958,24 @@ HD void leaf_round_limbs(const LeafRoundArgs &a, size_t bk, size_t i, int j0, bo
     for (int jj = 0; jj < JC; jj++)
         if (j0 + jj < a.L) st2(a.accH + (bk * a.L + j0 + jj) * n + i, ac[jj]);
 }
-HD void leaf_round_body(const LeafRoundArgs &a, size_t gid)
+template <int M> HD void leaf_round_body_m(const LeafRoundArgs &a, size_t gid)
 {
     const size_t n = (size_t)1 << a.logn;
     const size_t i = (gid & ((n >> 1) - 1)) << 1;
     const size_t bk = gid >> (a.logn - 1);   // (item, k)
     if (bk >= (size_t)a.B * 2) return;
     const bool with_c0 = !(bk & 1);
-    for (int j0 = 0; j0 < a.L; j0 += 4) leaf_round_limbs<4>(a, bk, i, j0, with_c0);
+    for (int j0 = 0; j0 < a.L; j0 += 4) leaf_round_limbs<4, M>(a, bk, i, j0, with_c0);
+}
+HD void leaf_round_body(const LeafRoundArgs &a, size_t gid)
+{
+    static_assert(HHE_LEAF_GROUP == 4, "leaf_round_body dispatches on m = 1..4");
+    switch (a.m) {
+    case 1: leaf_round_body_m<1>(a, gid); break;
+    case 2: leaf_round_body_m<2>(a, gid); break;
+    case 3: leaf_round_body_m<3>(a, gid); break;
+    default: leaf_round_body_m<4>(a, gid); break;
+    }
 }
 
 // gid over [B][K][N/2] (as ks_mac_body_t): the inner products of m leaf children of one node, see KsMacLeavesArgs
