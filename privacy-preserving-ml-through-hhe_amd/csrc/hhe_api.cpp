@@ -1105,11 +1105,30 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
     const int L = c->L, K = c->K;
     const size_t n = c->n, ln = (size_t)L * n;
     const u32 einv = (u32)nt_invmod(elt, 2 * n);  // galois(c0) is gathered on the fly (leaf_round_kernel for leaves, the KSF epilogue otherwise)
+    u64 *Usp = c->w->ws_S + B * 2 * L * n;  // split output [B][2][L][N] | [B][2][N] (non-leaf children)
+    const u64 *key_s = nullptr;
+    if (!leaf && c->fc_row_fused && use_row_kernel(c) && ensure_key_shoup(c, it->second, &key_s) == HHE_OK) {
+        // N >= 4096: inner product over the shared digits and the inverse row pass of all 2K sums in one kernel (the sums never make a
+        // round trip), then the strided inverse passes with the mod-down, the Galois-gathered c0 and the running sum in the data limbs' store
+        KsRowArgs x;
+        memset(&x, 0, sizeof(x));
+        x.key = it->second; x.key_s = key_s; x.U0 = c->w->ws_S; x.U1 = c->w->ws_S + (size_t)L * n; x.u_stride = (size_t)2 * L * n; x.Usp = Usp;
+        x.B = (int)B; x.L = L; x.K = K; x.T = tp; x.corr = corr; x.perm_elt = elt;
+        NttArgs g = ntt_args(c, nullptr, nullptr, 0, 0, K);
+        if (k_ks_perm_row(g, x, c->w->stream)) return dev_fail("fc: key-switch row kernel");
+        NttArgs as = ntt_args(c, Usp, Usp, B * 2, K - 1, 1);
+        as.store_op = STORE_RSP;
+        k_ntt_pass(as, true, true, c->w->stream);
+        NttArgs ad = ntt_args(c, c->w->ws_S, c->w->ws_S, B * 2 * L, 0, L);
+        ad.store_op = STORE_KSF; ad.aux_r = Usp; ad.aux_in = parent; ad.base_stride = 2 * ln; ad.base_mask = 1; ad.gal_einv = einv; ad.aux_out = cur;
+        ad.acc = add_to;
+        k_ntt_pass(ad, true, true, c->w->stream);
+        return HHE_OK;
+    }
     KsMacArgs m;
     memset(&m, 0, sizeof(m));
     m.T = tp; m.key = it->second; m.S = c->w->ws_S; m.mods = c->d_mods; m.logn = c->logn; m.B = (int)B; m.L = L; m.K = K;
     m.perm_elt = elt; m.corr = corr;
-    u64 *Usp = c->w->ws_S + B * 2 * L * n;  // split output [B][2][L][N] | [B][2][N] (non-leaf children)
     if (leaf) m.s_acc = leaf->accS;
     else m.S_sp = Usp;
     k_ks_mac(m, c->w->stream);

@@ -204,6 +204,11 @@ struct KsRowArgs {
     const u64 *const *mul_ptrs;
     size_t mul_shift;
     size_t mul_s_off;    // > 0: Shoup quotients of the multiplier table at this word offset behind it
+    // FC shared digits (ks_perm_row_kernel; U0 / U1 / Usp as in the generic key switch): T [B][L][K][N] = the COMPLETE digit transforms of the
+    // node's un-rotated c1, read through the NTT-domain Galois map of perm_elt; corr [2][K][N] is added to the sums (KsCorrArgs)
+    const u64 *T;
+    const u64 *corr;
+    u32 perm_elt;
 };
 
 // Correction of the shared-digit key switch (DESIGN.md "FC rotation trie"): the digit d_I of galois_g(c1) differs from

@@ -89,6 +89,7 @@ struct hhe_ctx {
     u64 fc_fallbacks = 0;          // how often the shared-digit path had to be recomputed exactly
     int fc_shared = 1;             // FC rotation trie: children of a node share the digit transforms of its c1 (HHE_FC_SHARED; 2 = force the fallback, tests)
     int fc_leaf_group = HHE_LEAF_GROUP;  // FC rotation trie: leaf key switches per launch, across the nodes whose digits are resident (HHE_FC_LEAFGROUP; 1 = one leaf at a time)
+    int fc_row_fused = 1;          // FC non-leaf children at N >= 4096: inner product + inverse row pass in one kernel (ks_perm_row_kernel; HHE_FC_ROWFUSED=0: separate launches)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
     size_t fc_chunk = 160;         // items per internal chunk of hhe_fc_row (0 = whole batch); ms per MNIST sample (784x10, 16 samples): 64: 60.5, 80: 60.6, 96: 60.6, 128: 59.5, 160: 58.4
                                    // (round 1: 40: 67.1, 80: 64.9, 160: 64.0); the trie's small launches (2 polynomials per item) want more than one round of workgroups

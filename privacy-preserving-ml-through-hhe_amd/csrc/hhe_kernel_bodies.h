@@ -867,6 +867,57 @@ HD void ks_row_mac_phase(const KsRowArgs &x, const NttArgs &fa, int bx, int b, i
         }
     }
 }
+// The same products for a child of an FC trie node (shared digits): the digit transforms T of the node's UN-rotated c1 are complete
+// (both passes) and read through the NTT-domain Galois map -- no tile, no rounds; the map sends aligned pairs to aligned pairs (possibly
+// swapped), so a lane's pair is one 16-byte load.  The correction table of the key (KsCorrArgs) joins the sums after the last digit.
+template <int CM, int CC>
+HD void ks_row_mac_gather(const KsRowArgs &x, const NttArgs &fa, int bx, int b, int J, int I, int tid, u64 *acc0, u64 *acc1)
+{
+    const NttGeom g = ntt_geom<CM, CC>(fa, bx, J);
+    const ModDev m = mod_at_u(fa.mods, J);
+    const u64 nq = m.nq;
+    const size_t kofs = (((size_t)I * 2) * x.K + J) * g.n, kstep = (size_t)x.K * g.n;
+    const u64 *T = x.T + (((size_t)b * x.L + I) * x.K + J) * g.n;
+    const bool fold = (I % 3) == 2 && I != x.L - 1;
+    U2 t[KSROW_NP], k0[KSROW_NP], k0s[KSROW_NP], k1[KSROW_NP], k1s[KSROW_NP];
+#pragma unroll
+    for (int k = 0; k < KSROW_NP; k++) {   // every gathered pair of the digit is requested before the first product
+        const u32 p0 = ntt_perm_index((u32)ks_row_idx<CM, CC>(fa, g, tid, k).gi, fa.logn, x.perm_elt);
+        t[k] = ld2(T + (p0 & ~1u));
+        if (p0 & 1) t[k] = U2{t[k].b, t[k].a};
+    }
+    auto request = [&](int k) {
+        const int gi = ks_row_idx<CM, CC>(fa, g, tid, k).gi;
+        k0[k] = ld2(x.key + kofs + gi); k0s[k] = ld2(x.key_s + kofs + gi);
+        k1[k] = ld2(x.key + kofs + kstep + gi); k1s[k] = ld2(x.key_s + kofs + kstep + gi);
+    };
+    request(0);
+#pragma unroll
+    for (int k = 0; k < KSROW_NP; k++) {
+        if (k + 1 < KSROW_NP) request(k + 1);
+        acc0[2 * k] = add_nw(acc0[2 * k], shoup_lazy_t(t[k].a, k0[k].a, k0s[k].a, nq));
+        acc0[2 * k + 1] = add_nw(acc0[2 * k + 1], shoup_lazy_t(t[k].b, k0[k].b, k0s[k].b, nq));
+        acc1[2 * k] = add_nw(acc1[2 * k], shoup_lazy_t(t[k].a, k1[k].a, k1s[k].a, nq));
+        acc1[2 * k + 1] = add_nw(acc1[2 * k + 1], shoup_lazy_t(t[k].b, k1[k].b, k1s[k].b, nq));
+        if (fold) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                acc0[2 * k + e] = pm_fold(acc0[2 * k + e], m);
+                acc1[2 * k + e] = pm_fold(acc1[2 * k + e], m);
+            }
+        }
+    }
+    if (I == x.L - 1) {   // + corr[k][J] (canonical words): the sums stay below 2q + 3 * 4q + q
+        const u64 *e0 = x.corr + ((size_t)0 * x.K + J) * g.n, *e1 = x.corr + ((size_t)1 * x.K + J) * g.n;
+#pragma unroll
+        for (int k = 0; k < KSROW_NP; k++) {
+            const int gi = ks_row_idx<CM, CC>(fa, g, tid, k).gi;
+            const U2 c0 = ld2(e0 + gi), c1 = ld2(e1 + gi);
+            acc0[2 * k] = add_nw(acc0[2 * k], c0.a); acc0[2 * k + 1] = add_nw(acc0[2 * k + 1], c0.b);
+            acc1[2 * k] = add_nw(acc1[2 * k], c1.a); acc1[2 * k + 1] = add_nw(acc1[2 * k + 1], c1.b);
+        }
+    }
+}
 // sums -> LDS in [0,2q) (input range of the inverse rounds); optionally also canonical to global (S_0[j])
 template <int CM, int CC>
 HD void ks_row_flush_phase(const NttArgs &fa, int bx, int J, int tid, u64 *lds, const u64 *acc, u64 *canon_out)

@@ -398,6 +398,58 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_row_kernel(NttA
     }
     KS_STAMP_FLUSH();
 }
+// A child of an FC trie node from the node's shared digit transforms: key inner product over the digits read through the Galois map
+// (ks_row_mac_gather) + the inverse row pass of all 2K sums, one (item, key limb, row tile) per single-wave workgroup -- the sums never
+// make a round trip (before: ks_mac_kernel wrote S, a row-pass launch read it back).  Same block order and outputs as the generic
+// variant of ks_row_kernel (U0 / U1 / Usp).
+template <int LOGM>
+__global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_perm_row_kernel(NttArgs a, KsRowArgs x)
+{
+    constexpr bool TWL = LOGM == 8;
+    __shared__ u64 lds[KSROW_LDS + (TWL ? KSROW_TWL : 0)];
+    u64 *const twl = TWL ? lds + KSROW_LDS : nullptr;
+    constexpr int CC = KSROW_TILE_LOG - LOGM, T = KSROW_THREADS, SCH = KSROW_SCHED;
+    const unsigned tmask = (1u << a.tiles_log) - 1;
+    const unsigned rr = blockIdx.x >> 3, uu = (rr / (unsigned)x.B) * 8 + (blockIdx.x & 7);
+    const int b = (int)(rr % (unsigned)x.B), J = (int)(uu >> a.tiles_log), bx = (int)(uu & tmask), tid = threadIdx.x;
+    if (J >= x.K) return;  // the grid is padded to a multiple of eight (limb, tile) units
+    const size_t n = (size_t)1 << a.logn;
+    u64 acc0[2 * KSROW_NP], acc1[2 * KSROW_NP];
+#pragma unroll
+    for (int k = 0; k < 2 * KSROW_NP; k++) { acc0[k] = 0; acc1[k] = 0; }
+    if (TWL) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, tid, twl);
+    for (int I = 0; I < x.L; I++) ks_row_mac_gather<LOGM, CC>(x, a, bx, b, J, I, tid, acc0, acc1);
+    u64 *const out0 = J < x.L ? x.U0 + (size_t)b * x.u_stride + (size_t)J * n : x.Usp + ((size_t)b * 2 + 0) * n;
+    u64 *const out1 = J < x.L ? x.U1 + (size_t)b * x.u_stride + (size_t)J * n : x.Usp + ((size_t)b * 2 + 1) * n;
+    ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc0, nullptr);
+    tile_sync<T>();
+    ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
+    ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, out0);
+    tile_sync<T>();
+    ks_row_flush_phase<LOGM, CC>(a, bx, J, tid, lds, acc1, nullptr);
+    tile_sync<T>();
+    ntt_tile_rounds<LOGM, false, true, CC, T, SCH, TWL, true>(a, bx, J, lds, twl);
+    ks_row_store_phase<LOGM, CC>(a, bx, J, tid, lds, out1);
+}
+int k_ks_perm_row(const NttArgs &a0, const KsRowArgs &x, rt_stream s)
+{
+    NttArgs a = a0;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    a.logm = n2;
+    a.logc = KSROW_TILE_LOG - n2;
+    a.tiles_log = n1 - a.logc;
+    const size_t units = ((size_t)x.K << a.tiles_log);   // (limb, tile) units; with tiles_log >= 3 a multiple of eight
+    dim3 grid((unsigned)(((units + 7) & ~(size_t)7) * x.B));
+    hipStream_t st = (hipStream_t)s;
+    switch (n2) {
+    case 6: hipLaunchKernelGGL((ks_perm_row_kernel<6>), grid, dim3(KSROW_THREADS), 0, st, a, x); break;
+    case 7: hipLaunchKernelGGL((ks_perm_row_kernel<7>), grid, dim3(KSROW_THREADS), 0, st, a, x); break;
+    case 8: hipLaunchKernelGGL((ks_perm_row_kernel<8>), grid, dim3(KSROW_THREADS), 0, st, a, x); break;
+    default: snprintf(g_rt_err, sizeof(g_rt_err), "ks_perm_row: unsupported row pass size 2^%d", n2); return -1;
+    }
+    return 0;
+}
 int k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s)
 {
     NttArgs a = a0, c0;

@@ -44,6 +44,9 @@ void k_ntt2_fwd_first(const NttArgs &a1, const NttArgs &a2, rt_stream s);  // fi
 // (nothing launched, rt_last_error() set) for an unsupported geometry.
 inline bool k_ks_row_supported(int logn) { const int n2 = logn - logn / 2; return logn >= 12 && n2 >= 6 && n2 <= 8; }
 int k_ks_row(const NttArgs &a, const KsRowArgs &x, const NttArgs *c0_row, rt_stream s);
+// FC shared digits: key inner product over the complete digit transforms x.T read through the Galois map of x.perm_elt (+ x.corr) and the
+// inverse row pass of all 2K sums into x.U0 / x.U1 / x.Usp; `a` carries the geometry and moduli (logn, mods, lazy8 = 1).  -1: unsupported size
+int k_ks_perm_row(const NttArgs &a, const KsRowArgs &x, rt_stream s);
 void k_elt(const EltArgs &a, int op, rt_stream s);
 void k_copy_items(const CopyItemsArgs &a, rt_stream s);
 void k_galois(const GaloisArgs &a, rt_stream s);

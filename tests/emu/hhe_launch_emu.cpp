@@ -192,6 +192,53 @@ int k_ks_row(const NttArgs &a0, const KsRowArgs &x, const NttArgs *c0_row, rt_st
     }
     return 0;
 }
+template <int LOGM>
+static void ks_perm_row_emu(const NttArgs &a, const KsRowArgs &x, int gx, int gy)
+{
+    constexpr int CC = KSROW_TILE_LOG - LOGM, T = KSROW_THREADS, SCH = KSROW_SCHED;
+    const size_t n = (size_t)1 << a.logn;
+#pragma omp parallel
+    {
+        constexpr bool TWL = LOGM == 8;
+        std::vector<u64> lds(KSROW_LDS + (TWL ? KSROW_TWL : 0));
+        u64 *const twl = TWL ? lds.data() + KSROW_LDS : nullptr;
+        std::vector<u64> acc0((size_t)T * 2 * KSROW_NP), acc1((size_t)T * 2 * KSROW_NP);
+#pragma omp for collapse(2)
+        for (int y = 0; y < gy; y++)
+            for (int bx = 0; bx < gx; bx++) {
+                const int b = y / x.K, J = y % x.K;
+                if (TWL) for (int t = 0; t < T; t++) ks_row_twiddle_fill<LOGM, CC>(a, bx, J, true, t, twl);
+                std::fill(acc0.begin(), acc0.end(), 0);
+                std::fill(acc1.begin(), acc1.end(), 0);
+                for (int I = 0; I < x.L; I++)
+                    for (int t = 0; t < T; t++) ks_row_mac_gather<LOGM, CC>(x, a, bx, b, J, I, t, &acc0[(size_t)t * 2 * KSROW_NP], &acc1[(size_t)t * 2 * KSROW_NP]);
+                auto inverse_to = [&](std::vector<u64> &acc, u64 *out) {
+                    for (int t = 0; t < T; t++) ks_row_flush_phase<LOGM, CC>(a, bx, J, t, lds.data(), &acc[(size_t)t * 2 * KSROW_NP], nullptr);
+                    tile_rounds_emu<LOGM, false, true, CC, T, SCH, TWL>(a, bx, J, lds.data(), twl);
+                    for (int t = 0; t < T; t++) ks_row_store_phase<LOGM, CC>(a, bx, J, t, lds.data(), out);
+                };
+                inverse_to(acc0, J < x.L ? x.U0 + (size_t)b * x.u_stride + (size_t)J * n : x.Usp + ((size_t)b * 2 + 0) * n);
+                inverse_to(acc1, J < x.L ? x.U1 + (size_t)b * x.u_stride + (size_t)J * n : x.Usp + ((size_t)b * 2 + 1) * n);
+            }
+    }
+}
+int k_ks_perm_row(const NttArgs &a0, const KsRowArgs &x, rt_stream)
+{
+    if (!a0.lazy8) { fprintf(stderr, "emu: k_ks_perm_row on a modulus without the pseudo-Mersenne form\n"); abort(); }
+    NttArgs a = a0;
+    int n1, n2;
+    ntt_split(a.logn, n1, n2);
+    a.logm = n2;
+    a.logc = KSROW_TILE_LOG - n2;
+    const int gx = 1 << (n1 - a.logc), gy = x.B * x.K;
+    switch (n2) {
+    case 6: ks_perm_row_emu<6>(a, x, gx, gy); break;
+    case 7: ks_perm_row_emu<7>(a, x, gx, gy); break;
+    case 8: ks_perm_row_emu<8>(a, x, gx, gy); break;
+    default: return -1;
+    }
+    return 0;
+}
 void k_ntt2_fwd(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, false, s); k_ntt(a2, false, s); }
 void k_ntt2_inv(const NttArgs &a1, const NttArgs &a2, rt_stream s) { k_ntt(a1, true, s); k_ntt(a2, true, s); }
 #define LOOP(total, call)                                         \

@@ -399,6 +399,9 @@ def test_fc_row_variants_full_tiles(orc, api, emu_lib, mem, monkeypatch):
     Galois-gathered base) and the leaf sums (STORE_RACC with q_sp * galois(c0)) on the tile geometry the GPU runs"""
     S = Setup(orc, 12, [50] * 3, all_galois=True)
     pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=emu_lib), S, orc, mem, monkeypatch, n_in=21)
+    # non-leaf children without ks_perm_row_kernel (inner product and inverse row passes as separate launches)
+    monkeypatch.setenv("HHE_FC_ROWFUSED", "0")
+    pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=emu_lib), S, orc, mem, monkeypatch, n_in=21)
 
 
 @pytest.mark.parametrize("pattern", ["max", "alt", "max_keys"])
