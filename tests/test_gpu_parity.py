@@ -394,6 +394,16 @@ def test_fc_row_shared_digit_variants(orc, api, lib, mem, monkeypatch):
     pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=lib), S, orc, mem, monkeypatch, n_in=100)
 
 
+def test_fc_row_variants_bench_shape_n32768(orc, api, lib, mem, monkeypatch):
+    """the FC's execution variants at the bench's parameters (N = 2^15, 4 x 60-bit primes: L = 3, K = 4): ks_perm_row_kernel<8> with the
+    LDS twiddle heap, leaf groups across trie nodes, the slot pool -- every word against the oracle; then the same without the fused
+    row kernel of the non-leaf children (HHE_FC_ROWFUSED=0)"""
+    S = Setup(orc, 15, [60] * 4, all_galois=True)
+    pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=lib), S, orc, mem, monkeypatch, n_in=14)
+    monkeypatch.setenv("HHE_FC_ROWFUSED", "0")
+    pc.check_fc_variants(lambda: api.Context(S.logn, S.q, S.t, lib=lib), S, orc, mem, monkeypatch, n_in=14)
+
+
 def test_config4_two_layer_chain(orc, api, lib, mem):
     """BASELINE config 4: the reference's ECG first-layer weights (weights/ecg/ecg_512/fc1_weight_50epochs_bz4.csv, fixture
     tests/golden/ecg_fc1.json) on seeded synthetic 128-word inputs in [0,255] (the reference's ECG inputs are missing)."""
