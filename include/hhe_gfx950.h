@@ -71,7 +71,7 @@ int hhe_ctx_sync(hhe_ctx *c);
 int hhe_ctx_profile(hhe_ctx *c, int enable);
 int hhe_ctx_profile_read(hhe_ctx *c, char *kernel_name, size_t name_cap, uint64_t *launches, double *total_ms, uint64_t *items);
 /* derived parameters, for cross-checking against SEAL's context: what in
- * {"root" i<K, "bsk" i<=L (B_0.., m_sk), "gamma", "galois_elt" i=step, "fc_fallbacks"} */
+ * {"root" i<K, "bsk" i<=L (B_0.., m_sk), "gamma", "galois_elt" i=step, "fc_fallbacks", "fc_csum_closes"} */
 uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i);
 
 /* ---- keys.  Key words must be reduced modulo their coefficient primes (what SEAL's safe load checks, is_data_valid_for):

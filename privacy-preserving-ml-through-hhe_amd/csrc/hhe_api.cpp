@@ -1085,12 +1085,14 @@ int fc_corr(hhe_ctx *c, u32 elt, const u64 *key, const u64 **out)
     return HHE_OK;
 }
 // digit transforms of the un-rotated c1 of `parent` into tp ([B][L][K][N], lazy range)
-void fc_parent_digits(hhe_ctx *c, const u64 *parent, u64 *tp, size_t B)
+// sp_only: the transforms modulo the special prime alone, tp [B][L][N] (a node whose children are all leaves of the c1-sum scheme)
+void fc_parent_digits(hhe_ctx *c, const u64 *parent, u64 *tp, size_t B, bool sp_only = false)
 {
     const int L = c->L, K = c->K;
     const size_t ln = (size_t)L * c->n;
-    NttArgs a = ntt_args(c, parent + ln, tp, B * L * K, 0, K);
-    a.src_div = K; a.src_item_polys = L * K; a.src_item_stride = 2 * ln; a.load_op = LOAD_DIGIT; a.digit_reduce = c->digit_reduce;
+    NttArgs a = sp_only ? ntt_args(c, parent + ln, tp, B * L, K - 1, 1) : ntt_args(c, parent + ln, tp, B * L * K, 0, K);
+    a.src_div = sp_only ? 1 : K; a.src_item_polys = sp_only ? L : L * K; a.src_item_stride = 2 * ln; a.load_op = LOAD_DIGIT;
+    a.digit_reduce = c->digit_reduce;
     a.store_op = STORE_LAZY; a.zero_flag = c->w->zero_flag;
     k_ntt(a, false, c->w->stream);
 }
@@ -1158,16 +1160,94 @@ struct FcWalk {
     const FcLeafAcc *acc;
     size_t B;
     int group, max_slots;
+    bool csum;   // data limbs of the leaves through per-element sums of their parents' c1 (CsumArgs); the leaf queue then carries the special limb only
     struct Leaf { int slot; const u64 *parent; u32 elt; } q[HHE_LEAF_GROUP];
     int m = 0;
+    struct ElemSum {   // one per Galois element among the leaves
+        u32 elt;
+        u64 *sums;      // [B][L][N]
+        int count = 0;  // leaves summed into `sums`
+        int npend = 0;  // parents queued for the next csum_add launch
+        int pend_slot[HHE_LEAF_GROUP];
+        const u64 *pend_c1[HHE_LEAF_GROUP];
+    };
+    std::vector<ElemSum> esums;
+    static constexpr int CSUM_MAX = 15;   // integer sums of 15 terms below 2^60 fit 64 bits
+
+    int csum_add_pending(ElemSum &e)
+    {
+        if (!e.npend) return HHE_OK;
+        Lane &ln = *c->w;
+        CsumArgs a;
+        memset(&a, 0, sizeof(a));
+        a.sums = e.sums; a.src_stride = 2 * (size_t)c->L * c->n; a.m = e.npend; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = c->L; a.K = c->K;
+        for (int l = 0; l < e.npend; l++) a.src[l] = e.pend_c1[l];
+        k_csum_add(a, ln.stream);
+        for (int l = 0; l < e.npend; l++) ln.fc_slots[e.pend_slot[l]].refs--;
+        e.count += e.npend;
+        e.npend = 0;
+        return HHE_OK;
+    }
+    // closes a sum: digits of galois(sum) mod every key-level prime, their transforms, ONE inner product into accS
+    int csum_close(ElemSum &e)
+    {
+        int rc = csum_add_pending(e);
+        if (rc || !e.count) return rc;
+        Lane &ln = *c->w;
+        auto it = c->gks->gk.find(e.elt);
+        if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
+        const int L = c->L, K = c->K;
+        CsumArgs a;
+        memset(&a, 0, sizeof(a));
+        a.sums = e.sums; a.out = ln.ws_T; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K;
+        a.einv = (u32)nt_invmod(e.elt, 2 * c->n); a.count = (u32)e.count;
+        k_csum_digits(a, ln.stream);
+        NttArgs t = ntt_args(c, ln.ws_T, ln.ws_T, B * L * K, 0, K);
+        t.store_op = STORE_LAZY;
+        k_ntt(t, false, ln.stream);
+        KsMacArgs mm;
+        memset(&mm, 0, sizeof(mm));
+        mm.T = ln.ws_T; mm.key = it->second; mm.S = ln.ws_S; mm.mods = c->d_mods; mm.logn = c->logn; mm.B = (int)B; mm.L = L; mm.K = K;
+        mm.s_acc = acc->accS; mm.perm_elt = 1; mm.corr = c->d_zero_corr;  // the digits are those of the ROTATED sum: identity map, no correction
+        k_ks_mac(mm, ln.stream);
+        rt_memset(e.sums, 0, B * (size_t)L * c->n * 8, ln.stream);
+        e.count = 0;
+        c->fc_csum_closes++;
+        return HHE_OK;
+    }
+    int csum_leaf(int slot, const u64 *parent, u32 elt)
+    {
+        Lane &ln = *c->w;
+        ElemSum *e = nullptr;
+        for (auto &x : esums) if (x.elt == elt) e = &x;
+        if (!e) {
+            if (ln.csum_bufs.size() <= esums.size()) {
+                u64 *p = (u64 *)rt_malloc(ln.fc_slot_cap * (size_t)c->L * c->n * 8);
+                if (!p) return dev_fail("hhe_fc_row workspace");
+                ln.csum_bufs.push_back(p);
+            }
+            ElemSum x;
+            x.elt = elt; x.sums = ln.csum_bufs[esums.size()];
+            rt_memset(x.sums, 0, B * (size_t)c->L * c->n * 8, ln.stream);
+            esums.push_back(x);
+            e = &esums.back();
+        }
+        int rc;
+        if (e->count + e->npend >= CSUM_MAX && (rc = csum_close(*e))) return rc;
+        e->pend_slot[e->npend] = slot; e->pend_c1[e->npend] = parent + (size_t)c->L * c->n;
+        ++e->npend;
+        ln.fc_slots[slot].refs++;
+        if (e->npend == HHE_LEAF_GROUP) return csum_add_pending(*e);
+        return HHE_OK;
+    }
 
     int flush()
     {
         Lane &ln = *c->w;
         int rc = HHE_OK;
-        if (m > 0 && (group == 1 || m == 1)) {
+        if (m > 0 && !csum && (group == 1 || m == 1)) {
             for (int l = 0; l < m && !rc; l++) rc = fc_child_shared(c, q[l].parent, ln.fc_slots[q[l].slot].tp, q[l].elt, acc, nullptr, B);
-        } else if (m > 1) {
+        } else if (m > 0) {
             const int L = c->L, K = c->K;
             KsMacLeavesArgs a;
             memset(&a, 0, sizeof(a));
@@ -1177,11 +1257,12 @@ struct FcWalk {
                 auto it = c->gks->gk.find(q[l].elt);
                 if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
                 if ((rc = fc_corr(c, q[l].elt, it->second, &a.corr[l]))) return rc;
-                a.T[l] = ln.fc_slots[q[l].slot].tp; a.key[l] = it->second; a.perm_elt[l] = q[l].elt;
+                a.T[l] = ln.fc_slots[q[l].slot].tp; a.t_polys[l] = ln.fc_slots[q[l].slot].tp_polys; a.key[l] = it->second; a.perm_elt[l] = q[l].elt;
                 einv[l] = (u32)nt_invmod(q[l].elt, 2 * c->n);
                 parents[l] = q[l].parent;
             }
             a.S_sp = ln.ws_leaf; a.s_acc = acc->accS; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K; a.m = m;
+            a.sp_only = csum ? 1 : 0;
             if (k_ks_mac_leaves(a, ln.stream)) return fail(HHE_ERR_INVALID, "fc: leaf group");
             fc_leaf_round(c, ln.ws_leaf, true, parents, einv, m, *acc, B);
         }
@@ -1198,8 +1279,8 @@ struct FcWalk {
                 if (ln.fc_slots[i].refs == 0) { ln.fc_slots[i].refs = 1; *slot = (int)i; return HHE_OK; }
             if ((int)ln.fc_slots.size() < max_slots) {
                 Lane::FcSlot sl;
-                sl.tp = (u64 *)rt_malloc(B * (size_t)c->L * c->K * c->n * 8);
-                sl.ct = (u64 *)rt_malloc(B * c->ct_words() * 8);
+                sl.tp = (u64 *)rt_malloc(ln.fc_slot_cap * (size_t)c->L * c->K * c->n * 8);   // sized for the pool's capacity, not this call's batch
+                sl.ct = (u64 *)rt_malloc(ln.fc_slot_cap * c->ct_words() * 8);
                 if (!sl.tp || !sl.ct) { rt_free(sl.tp); rt_free(sl.ct); return dev_fail("hhe_fc_row workspace"); }
                 sl.refs = 1;
                 ln.fc_slots.push_back(sl);
@@ -1207,6 +1288,7 @@ struct FcWalk {
                 return HHE_OK;
             }
             int rc = flush();  // the queued leaves hold the remaining slots
+            for (auto &e : esums) if (!rc) rc = csum_add_pending(e);
             if (rc) return rc;
         }
         return fail(HHE_ERR_INVALID, "hhe_fc_row: slot pool");
@@ -1216,11 +1298,18 @@ struct FcWalk {
     {
         if (trie[node].kids.empty()) return HHE_OK;
         Lane &ln = *c->w;
-        fc_parent_digits(c, parent, ln.fc_slots[slot].tp, B);
+        auto is_leaf = [&](int kid) { return acc && trie[kid].kids.empty() && trie[kid].mult == 1; };
+        bool only_leaves = csum;
+        for (int kid : trie[node].kids) only_leaves = only_leaves && is_leaf(kid);
+        // a node whose children are all leaves needs its digit transforms modulo the special prime only (their data limbs come from the c1 sums)
+        fc_parent_digits(c, parent, ln.fc_slots[slot].tp, B, only_leaves);
+        ln.fc_slots[slot].tp_polys = only_leaves ? 1 : c->K;
         int rc;
         for (int kid : trie[node].kids) {
-            if (!(acc && trie[kid].kids.empty() && trie[kid].mult == 1)) continue;
-            q[m].slot = slot; q[m].parent = parent; q[m].elt = galois_elt_from_step(c, trie[kid].term);
+            if (!is_leaf(kid)) continue;
+            const u32 elt = galois_elt_from_step(c, trie[kid].term);
+            if (csum && (rc = csum_leaf(slot, parent, elt))) return rc;
+            q[m].slot = slot; q[m].parent = parent; q[m].elt = elt;
             ++m;
             ln.fc_slots[slot].refs++;
             if (m >= group && (rc = flush())) return rc;
@@ -1247,14 +1336,25 @@ int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int max_depth, c
         rt_sync(ln.stream);
         for (auto &sl : ln.fc_slots) { rt_free(sl.tp); rt_free(sl.ct); }
         ln.fc_slots.clear();
+        for (u64 *p : ln.csum_bufs) rt_free(p);
+        ln.csum_bufs.clear();
         ln.fc_slot_cap = B;
     }
     for (auto &sl : ln.fc_slots) sl.refs = 0;
     const int group = c->L <= 4 ? std::min(HHE_LEAF_GROUP, c->fc_leaf_group) : 1;  // k_ks_mac_leaves is instantiated for L <= 4
-    FcWalk w{c, trie, out, acc, B, group, max_depth + 1 + group};
+    // the c1-sum scheme serves leaf sums (acc) with a group kernel (L <= 4); its zero table stands in for the correction of the closing product
+    bool csum = acc && c->fc_csum && c->L <= 4;
+    if (csum && !c->d_zero_corr) {
+        const size_t bytes = (size_t)2 * c->K * c->n * 8;
+        if (!(c->d_zero_corr = (u64 *)rt_malloc(bytes))) return dev_fail("hhe_fc_row workspace");
+        rt_memset(c->d_zero_corr, 0, bytes, ln.stream);
+    }
+    FcWalk w{c, trie, out, acc, B, group, max_depth + 1 + group + 2 * HHE_LEAF_GROUP, csum};
+    w.esums.reserve(64);
     int root = -1, rc = w.acquire(&root);
     if (!rc) rc = w.walk(0, prod, root);
     if (!rc) rc = w.flush();
+    for (auto &e : w.esums) if (!rc) rc = w.csum_close(e);
     return rc;
 }
 int fc_dfs(hhe_ctx *c, const std::vector<NafNode> &trie, int node, int depth, const u64 *parent, u64 *bufs, u64 *out,

@@ -264,10 +264,30 @@ struct KsMacLeavesArgs {
     u64 *s_acc;        // [B][2][L][N]
     const ModDev *mods;
     int logn, B, L, K, m;
-    const u64 *T[HHE_LEAF_GROUP];     // [B][L][K][N] digit transforms of the un-rotated c1 of leaf l's parent
+    const u64 *T[HHE_LEAF_GROUP];     // [B][L][K][N] digit transforms of the un-rotated c1 of leaf l's parent ([B][L][N] when t_polys[l] == 1: special limb only)
+    int t_polys[HHE_LEAF_GROUP];      // polynomials per digit in T[l]: K, or 1 for a parent whose children are all leaves
+    int sp_only;                      // 1: only the special-limb sums (gid over [B][N/2]); the data-limb sums of the leaves come from the per-element c1 sums (CsumArgs)
     const u64 *key[HHE_LEAF_GROUP];   // [L][2][K][N]
     const u64 *corr[HHE_LEAF_GROUP];  // [2][K][N]
     u32 perm_elt[HHE_LEAF_GROUP];
+};
+
+// FC leaves, data limbs.  The inner product of a key switch is linear in the DIGITS as integers, and every leaf with the same Galois
+// element g uses the same key: sum_l sum_I NTT_J(d_I(galois_g(c1_l))) key_g[I][k][J] = sum_I NTT_J(D_I) key_g[I][k][J] with D_I = the integer
+// sum of the leaves' digits.  A digit of galois_g(c1) is c1_I at the mapped position, or q_I - c1_I where the map flips the sign (c1_I != 0:
+// the shared-digit zero flag covers the rest), so D_I = galois_g applied to the integer sum of the UN-rotated limbs with `count` q_I - . at
+// the flipped positions.  csum_add: sums[b][I][.] += c1 limbs of up to HHE_LEAF_GROUP parents (64-bit integers: at most 15 terms of < 2^60);
+// csum_digits: out[b][I][J][.] = D_I mod q_J for the K key-level primes -- the digit transforms and ONE inner product per element follow.
+struct CsumArgs {
+    u64 *sums;          // [B][L][N] integer sums of un-rotated c1 limbs
+    const u64 *src[HHE_LEAF_GROUP];  // csum_add: parents' c1 (item b at src[l] + b * src_stride, [L][N])
+    size_t src_stride;
+    int m;              // csum_add: parents in this launch
+    u64 *out;           // csum_digits: [B][L][K][N]
+    const ModDev *mods;
+    int logn, B, L, K;
+    u32 einv;           // csum_digits: elt^-1 mod 2N
+    u32 count;          // csum_digits: leaves summed
 };
 
 struct KsFinishArgs {  // SURVEY A.4 mod-down; S already INTT'd (coefficient form)

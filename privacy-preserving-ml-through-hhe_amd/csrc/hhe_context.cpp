@@ -332,6 +332,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     if (const char *mm = getenv("HHE_MATMUL")) c->matmul_mode = atoi(mm);
     if (const char *e = getenv("HHE_BLOCK_CACHE_MB")) c->block_cache_limit = (size_t)std::max(0, atoi(e)) << 20;
     if (const char *e = getenv("HHE_FC_ROWFUSED")) c->fc_row_fused = atoi(e);
+    if (const char *e = getenv("HHE_FC_CSUM")) c->fc_csum = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFGROUP")) c->fc_leaf_group = std::max(1, std::min(HHE_LEAF_GROUP, atoi(e)));
     if (const char *e = getenv("HHE_FC_SHARED")) c->fc_shared = atoi(e);
@@ -363,6 +364,8 @@ static void free_lane(Lane &ln)
     rt_free(ln.ws_rot); ln.ws_rot = nullptr; ln.rot_cap = 0;
     for (auto &sl : ln.fc_slots) { rt_free(sl.tp); rt_free(sl.ct); }
     ln.fc_slots.clear(); ln.fc_slot_cap = 0;
+    for (u64 *p : ln.csum_bufs) rt_free(p);
+    ln.csum_bufs.clear();
     rt_free(ln.ws_leaf); ln.ws_leaf = nullptr; ln.leaf_cap = 0;
     rt_free((void *)ln.d_ptrs); ln.d_ptrs = nullptr; ln.ptr_cap = 0;
     for (auto &pr : ln.prof_ev) { rt_event_destroy(pr.first); rt_event_destroy(pr.second); }
@@ -435,6 +438,7 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
     for (hhe_keyset *ks : c->sets) { keyset_clear(ks); delete ks; }  // sets the caller did not destroy
     for (auto &kv : c->d_key_shoup) rt_free(kv.second);
     rt_free(c->d_feistel_mask);
+    rt_free(c->d_zero_corr);
     rt_free(c->d_blocks); rt_free(c->d_flags);
     rt_free(c->d_tables); rt_free(c->d_mods); rt_free(c->d_behz); rt_free(c->d_slot_map);
     delete c;
@@ -521,6 +525,7 @@ extern "C" uint64_t hhe_ctx_query(const hhe_ctx *c, const char *what, int i)
     if (w == "delta" && i >= 0 && i < c->L) return c->apl.delta[i];
     if (w == "slot_map" && i >= 0 && (size_t)i < c->n) return c->slot_map[i];
     if (w == "fc_fallbacks") return c->fc_fallbacks;
+    if (w == "fc_csum_closes") return c->fc_csum_closes;
     if (w == "block_cache_bytes") return c->block_bytes;
     if (w == "block_cache_entries") return c->blocks.size();
     return 0;

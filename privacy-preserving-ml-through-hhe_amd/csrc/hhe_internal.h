@@ -52,8 +52,9 @@ struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `c
     size_t rot_cap = 0;
     // FC shared digits: one slot per trie node that is still needed -- the digit transforms of its un-rotated c1 (tp [B][L][K][N]) and its
     // ciphertext (ct [B][2][L][N]); refs = 1 while the depth-first walk is below the node + 1 per queued leaf key switch that reads it
-    struct FcSlot { u64 *tp = nullptr, *ct = nullptr; int refs = 0; };
+    struct FcSlot { u64 *tp = nullptr, *ct = nullptr; int refs = 0; int tp_polys = 0; };  // tp_polys: K, or 1 when tp holds the special-prime transforms only
     std::vector<FcSlot> fc_slots;
+    std::vector<u64 *> csum_bufs;  // FC leaves: integer sums of parents' c1 per Galois element, [B][L][N] each (sized like the slots)
     size_t fc_slot_cap = 0;  // items the slots were sized for
     u64 *ws_leaf = nullptr;  // FC leaf groups: special-limb sums [B][2][G][N] | their inverse transforms [B][2][G][N], G = HHE_LEAF_GROUP
     size_t leaf_cap = 0;
@@ -90,6 +91,9 @@ struct hhe_ctx {
     int fc_shared = 1;             // FC rotation trie: children of a node share the digit transforms of its c1 (HHE_FC_SHARED; 2 = force the fallback, tests)
     int fc_leaf_group = HHE_LEAF_GROUP;  // FC rotation trie: leaf key switches per launch, across the nodes whose digits are resident (HHE_FC_LEAFGROUP; 1 = one leaf at a time)
     int fc_row_fused = 1;          // FC non-leaf children at N >= 4096: inner product + inverse row pass in one kernel (ks_perm_row_kernel; HHE_FC_ROWFUSED=0: separate launches)
+    u64 fc_csum_closes = 0;        // how many c1 sums were closed (digits + transforms + one inner product); diagnostics, hhe_ctx_query("fc_csum_closes")
+    int fc_csum = 1;               // FC leaves: data-limb sums through per-element integer sums of the parents' c1 (one inner product per element instead of one per leaf; HHE_FC_CSUM=0: per leaf)
+    u64 *d_zero_corr = nullptr;    // [2][K][N] zeros: the correction table of the closing product of a c1 sum (its digits are already those of the rotated sum)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
     size_t fc_chunk = 160;         // items per internal chunk of hhe_fc_row (0 = whole batch); ms per MNIST sample (784x10, 16 samples): 64: 60.5, 80: 60.6, 96: 60.6, 128: 59.5, 160: 58.4
                                    // (round 1: 40: 67.1, 80: 64.9, 160: 64.0); the trie's small launches (2 polynomials per item) want more than one round of workgroups

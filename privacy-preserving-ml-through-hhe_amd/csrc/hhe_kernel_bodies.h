@@ -1035,8 +1035,8 @@ template <int LL> HD void ks_mac_leaves_body(const KsMacLeavesArgs &a, size_t gi
     const size_t n = (size_t)1 << a.logn;
     const size_t i = (gid & ((n >> 1) - 1)) << 1;
     const size_t bj = gid >> (a.logn - 1);
-    const int J = (int)(bj % a.K);
-    const size_t b = bj / a.K;
+    const int J = a.sp_only ? a.K - 1 : (int)(bj % a.K);
+    const size_t b = a.sp_only ? bj : bj / a.K;
     if (b >= (size_t)a.B) return;
     ModDev m;
     m.q = mod_at_u(a.mods, J).q; m.r_lo = mod_at_u(a.mods, J).r_lo; m.r_hi = mod_at_u(a.mods, J).r_hi;
@@ -1047,10 +1047,11 @@ template <int LL> HD void ks_mac_leaves_body(const KsMacLeavesArgs &a, size_t gi
     for (int l = 0; l < a.m; l++) {
         const u32 p0 = ntt_perm_index((u32)i, a.logn, a.perm_elt[l]);
         const u64 *key = a.key[l], *corr = a.corr[l], *T = a.T[l];
+        const int tk = a.t_polys[l], tj = tk == 1 ? 0 : J;
         U2 t[LL], k0[LL], k1[LL];
 #pragma unroll
         for (int I = 0; I < LL; I++) {
-            t[I] = ld2(T + ((b * LL + I) * a.K + J) * n + (size_t)(p0 & ~1u));   // leaves of one parent re-read the same words: cached
+            t[I] = ld2(T + ((b * LL + I) * tk + tj) * n + (size_t)(p0 & ~1u));   // leaves of one parent re-read the same words: cached
             k0[I] = ld2(key + (((size_t)I * 2 + 0) * a.K + J) * n + i);
             k1[I] = ld2(key + (((size_t)I * 2 + 1) * a.K + J) * n + i);
         }
@@ -1073,6 +1074,40 @@ template <int LL> HD void ks_mac_leaves_body(const KsMacLeavesArgs &a, size_t gi
         }
     }
     if (data) { st2(q0, c0); st2(q1, c1); }
+}
+
+// gid over [B][L][N/2], see CsumArgs
+HD void csum_add_body(const CsumArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = (gid & ((n >> 1) - 1)) << 1;
+    const size_t bI = gid >> (a.logn - 1);
+    const size_t b = bI / a.L, I = bI % a.L;
+    if (b >= (size_t)a.B) return;
+    U2 s = ld2(a.sums + bI * n + i), v[HHE_LEAF_GROUP];
+#pragma unroll
+    for (int l = 0; l < HHE_LEAF_GROUP; l++)
+        if (l < a.m) v[l] = ld2(a.src[l] + b * a.src_stride + I * n + i);
+#pragma unroll
+    for (int l = 0; l < HHE_LEAF_GROUP; l++)
+        if (l < a.m) { s.a = add_nw(s.a, v[l].a); s.b = add_nw(s.b, v[l].b); }
+    st2(a.sums + bI * n + i, s);
+}
+HD void csum_digits_body(const CsumArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const u32 i = (u32)((gid & ((n >> 1) - 1)) << 1);
+    const size_t bI = gid >> (a.logn - 1);
+    const size_t b = bI / a.L, I = bI % a.L;
+    if (b >= (size_t)a.B) return;
+    const u64 *src = a.sums + bI * n;
+    const u64 cq = (u64)a.count * mod_at(a.mods, (int)I).q;   // count <= 15, q < 2^60
+    const u32 j0 = (u32)(((u64)i * a.einv) & (2 * n - 1)), j1 = (u32)((j0 + a.einv) & (2 * n - 1));
+    const u64 v0 = j0 < n ? src[j0] : sub_nn(cq, src[j0 - n]), v1 = j1 < n ? src[j1] : sub_nn(cq, src[j1 - n]);
+    for (int J = 0; J < a.K; J++) {
+        const ModDev mj = mod_at(a.mods, J);
+        st2(a.out + ((b * a.L + I) * a.K + J) * n + i, U2{reduce64(v0, mj), reduce64(v1, mj)});
+    }
 }
 
 // key-switch mod-down by the special prime with rounding: gid over [B][2][L][N]

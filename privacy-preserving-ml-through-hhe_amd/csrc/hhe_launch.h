@@ -56,6 +56,8 @@ void k_ks_corr(const KsCorrArgs &a, rt_stream s);
 void k_ks_finish(const KsFinishArgs &a, rt_stream s);
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s);
 void k_leaf_round(const LeafRoundArgs &a, rt_stream s);
+void k_csum_add(const CsumArgs &a, rt_stream s);      // FC leaves: integer sums of un-rotated c1 limbs per Galois element
+void k_csum_digits(const CsumArgs &a, rt_stream s);   // ... and the digits of galois(sum) mod every key-level prime
 int k_ks_mac_leaves(const KsMacLeavesArgs &a, rt_stream s);  // -1: L > 4 (the caller takes the per-leaf path)
 void k_add_plain(const AddPlainArgs &a, rt_stream s);
 void k_encode_scatter(const EncodeArgs &a, rt_stream s);

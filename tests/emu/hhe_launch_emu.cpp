@@ -272,7 +272,7 @@ void k_ks_mac(const KsMacArgs &a, rt_stream)
 }
 int k_ks_mac_leaves(const KsMacLeavesArgs &a, rt_stream)
 {
-    const size_t total = ((size_t)a.B * a.K) << (a.logn - 1);
+    const size_t total = ((size_t)a.B * (a.sp_only ? 1 : a.K)) << (a.logn - 1);
     switch (a.L) {
     case 1: LOOP(total, (ks_mac_leaves_body<1>(a, (size_t)g))); break;
     case 2: LOOP(total, (ks_mac_leaves_body<2>(a, (size_t)g))); break;
@@ -285,6 +285,8 @@ int k_ks_mac_leaves(const KsMacLeavesArgs &a, rt_stream)
 void k_ks_corr(const KsCorrArgs &a, rt_stream) { LOOP(((size_t)2 * a.K) << a.logn, ks_corr_body(a, (size_t)g)); }
 void k_ks_finish(const KsFinishArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, ks_finish_body(a, (size_t)g)); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, leaf_sum_body(a, (size_t)g)); }
+void k_csum_add(const CsumArgs &a, rt_stream) { LOOP(((size_t)a.B * a.L) << (a.logn - 1), csum_add_body(a, (size_t)g)); }
+void k_csum_digits(const CsumArgs &a, rt_stream) { LOOP(((size_t)a.B * a.L) << (a.logn - 1), csum_digits_body(a, (size_t)g)); }
 void k_leaf_round(const LeafRoundArgs &a, rt_stream) { LOOP(((size_t)a.B * 2) << (a.logn - 1), leaf_round_body(a, (size_t)g)); }
 void k_add_plain(const AddPlainArgs &a, rt_stream) { LOOP((size_t)a.B << a.logn, add_plain_body(a, (size_t)g)); }
 void k_encode_scatter(const EncodeArgs &a, rt_stream) { LOOP((size_t)a.B * a.count * (a.second_off >= 0 ? 2 : 1), encode_scatter_body(a, (size_t)g)); }

@@ -183,6 +183,33 @@ def test_fc_row_naf_trie_equals_sequential_rotations(orc, api, emu_lib, mem):
         assert n_in <= 300 or not (ref == ref2).all()
 
 
+def test_fc_row_leaf_data_limbs_through_c1_sums(orc, api, emu_lib, mem, monkeypatch):
+    """the data-limb sums of the leaf key switches come from per-Galois-element INTEGER sums of the parents' c1 (one inner product per
+    element; a sum is closed after 15 terms so that it stays below 2^64): with 400 inputs many leaves share an element, several sums are
+    closed early, and the words are the oracle's -- as they are with one inner product per leaf (HHE_FC_CSUM=0)"""
+    S = Setup(orc, 10, [50] * 4, all_galois=True)
+    O = S.O
+    rng = np.random.default_rng(9)
+    n_in, B = 400, 2
+    v, w = rng.integers(0, 4, n_in), rng.integers(-8, 9, n_in)
+    wc = O.encrypt(S.pk, O.encode(w), 52)
+    vi = np.stack([O.encrypt(S.pk, O.encode(v), 50 + b) for b in range(B)])
+    refs = [O.fc_row(vi[b], wc, S.rk, S.gk, n_in)[0] for b in range(B)]
+    for knob in ("1", "0"):
+        monkeypatch.setenv("HHE_FC_CSUM", knob)
+        X = api.Context(S.logn, S.q, S.t, lib=emu_lib)
+        S.load_keys(X)
+        out = mem.empty((B,) + O.ct_shape)
+        X.fc_row(mem.to_dev(vi), mem.to_dev(wc[None]), 1, n_in, out, B, relin_slot=0, default_galois_only=False)
+        got = mem.to_host(out)
+        for b in range(B):
+            assert (got[b] == refs[b]).all(), (knob, b)
+        closes = X.query("fc_csum_closes")
+        assert (closes > 10) if knob == "1" else closes == 0   # more closes than distinct elements: the 15-term bound was hit
+        assert X.query("fc_fallbacks") == 0
+        X.close()
+
+
 def test_decompose_record_mask_flatten(orc, api, emu_lib, mem):
     """BaseCSP::decompose on device: blocks -> mask(last) -> flatten for a batch of records, vs the oracle's op sequence"""
     S = Setup(orc, 10, [50] * 9, extra_steps=(-128, -256))
