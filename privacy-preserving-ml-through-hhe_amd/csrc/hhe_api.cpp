@@ -1165,7 +1165,8 @@ struct FcWalk {
     int m = 0;
     struct ElemSum {   // one per Galois element among the leaves
         u32 elt;
-        u64 *sums;      // [B][L][N]
+        u64 *sums;      // [B][L][N] integer sums of c1 limbs
+        u64 *sums0;     // [B][L][N] sums of c0 limbs mod q_j
         int count = 0;  // leaves summed into `sums`
         int npend = 0;  // parents queued for the next csum_add launch
         int pend_slot[HHE_LEAF_GROUP];
@@ -1180,7 +1181,7 @@ struct FcWalk {
         Lane &ln = *c->w;
         CsumArgs a;
         memset(&a, 0, sizeof(a));
-        a.sums = e.sums; a.src_stride = 2 * (size_t)c->L * c->n; a.m = e.npend; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = c->L; a.K = c->K;
+        a.sums = e.sums; a.sums0 = e.sums0; a.src_stride = 2 * (size_t)c->L * c->n; a.m = e.npend; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = c->L; a.K = c->K;
         for (int l = 0; l < e.npend; l++) a.src[l] = e.pend_c1[l];
         k_csum_add(a, ln.stream);
         for (int l = 0; l < e.npend; l++) ln.fc_slots[e.pend_slot[l]].refs--;
@@ -1202,6 +1203,9 @@ struct FcWalk {
         a.sums = e.sums; a.out = ln.ws_T; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K;
         a.einv = (u32)nt_invmod(e.elt, 2 * c->n); a.count = (u32)e.count;
         k_csum_digits(a, ln.stream);
+        a.sums0 = e.sums0; a.accH = acc->accH;
+        for (int j = 0; j < L; j++) { a.qsp_mod[j] = c->ksc.qsp_mod[j]; a.qsp_mod_s[j] = c->ksc.qsp_mod_s[j]; }
+        k_csum_c0(a, ln.stream);
         NttArgs t = ntt_args(c, ln.ws_T, ln.ws_T, B * L * K, 0, K);
         t.store_op = STORE_LAZY;
         k_ntt(t, false, ln.stream);
@@ -1210,7 +1214,7 @@ struct FcWalk {
         mm.T = ln.ws_T; mm.key = it->second; mm.S = ln.ws_S; mm.mods = c->d_mods; mm.logn = c->logn; mm.B = (int)B; mm.L = L; mm.K = K;
         mm.s_acc = acc->accS; mm.perm_elt = 1; mm.corr = c->d_zero_corr;  // the digits are those of the ROTATED sum: identity map, no correction
         k_ks_mac(mm, ln.stream);
-        rt_memset(e.sums, 0, B * (size_t)L * c->n * 8, ln.stream);
+        rt_memset(e.sums, 0, 2 * B * (size_t)L * c->n * 8, ln.stream);   // sums | sums0
         e.count = 0;
         c->fc_csum_closes++;
         return HHE_OK;
@@ -1222,19 +1226,19 @@ struct FcWalk {
         for (auto &x : esums) if (x.elt == elt) e = &x;
         if (!e) {
             if (ln.csum_bufs.size() <= esums.size()) {
-                u64 *p = (u64 *)rt_malloc(ln.fc_slot_cap * (size_t)c->L * c->n * 8);
+                u64 *p = (u64 *)rt_malloc(2 * ln.fc_slot_cap * (size_t)c->L * c->n * 8);
                 if (!p) return dev_fail("hhe_fc_row workspace");
                 ln.csum_bufs.push_back(p);
             }
             ElemSum x;
-            x.elt = elt; x.sums = ln.csum_bufs[esums.size()];
-            rt_memset(x.sums, 0, B * (size_t)c->L * c->n * 8, ln.stream);
+            x.elt = elt; x.sums = ln.csum_bufs[esums.size()]; x.sums0 = x.sums + B * (size_t)c->L * c->n;
+            rt_memset(x.sums, 0, 2 * B * (size_t)c->L * c->n * 8, ln.stream);
             esums.push_back(x);
             e = &esums.back();
         }
         int rc;
         if (e->count + e->npend >= CSUM_MAX && (rc = csum_close(*e))) return rc;
-        e->pend_slot[e->npend] = slot; e->pend_c1[e->npend] = parent + (size_t)c->L * c->n;
+        e->pend_slot[e->npend] = slot; e->pend_c1[e->npend] = parent;
         ++e->npend;
         ln.fc_slots[slot].refs++;
         if (e->npend == HHE_LEAF_GROUP) return csum_add_pending(*e);
@@ -1259,7 +1263,7 @@ struct FcWalk {
                 if ((rc = fc_corr(c, q[l].elt, it->second, &a.corr[l]))) return rc;
                 a.T[l] = ln.fc_slots[q[l].slot].tp; a.t_polys[l] = ln.fc_slots[q[l].slot].tp_polys; a.key[l] = it->second; a.perm_elt[l] = q[l].elt;
                 einv[l] = (u32)nt_invmod(q[l].elt, 2 * c->n);
-                parents[l] = q[l].parent;
+                parents[l] = csum ? nullptr : q[l].parent;   // the c0 terms of the leaves come from the per-element sums
             }
             a.S_sp = ln.ws_leaf; a.s_acc = acc->accS; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K; a.m = m;
             a.sp_only = csum ? 1 : 0;

@@ -278,10 +278,16 @@ struct KsMacLeavesArgs {
 // the shared-digit zero flag covers the rest), so D_I = galois_g applied to the integer sum of the UN-rotated limbs with `count` q_I - . at
 // the flipped positions.  csum_add: sums[b][I][.] += c1 limbs of up to HHE_LEAF_GROUP parents (64-bit integers: at most 15 terms of < 2^60);
 // csum_digits: out[b][I][J][.] = D_I mod q_J for the K key-level primes -- the digit transforms and ONE inner product per element follow.
+// The leaves' q_sp * galois_g(c0) terms are linear mod q_j outright: sums0 collects the un-rotated c0 limbs of the same parents (mod q_j),
+// and csum_c0 adds q_sp * galois_g(sums0) into accH once per close -- the per-leaf coefficient-domain gather of c0 (8 bytes per cache
+// line) leaves the rounding kernel.
 struct CsumArgs {
     u64 *sums;          // [B][L][N] integer sums of un-rotated c1 limbs
-    const u64 *src[HHE_LEAF_GROUP];  // csum_add: parents' c1 (item b at src[l] + b * src_stride, [L][N])
+    u64 *sums0;         // [B][L][N] sums of un-rotated c0 limbs mod q_j (null: not collected)
+    const u64 *src[HHE_LEAF_GROUP];  // csum_add: parents' ciphertexts (item b at src[l] + b * src_stride: c0 limbs [L][N], then c1 limbs [L][N])
     size_t src_stride;
+    u64 *accH;          // csum_c0: [B][2][L][N]
+    u64 qsp_mod[HHE_MAXL], qsp_mod_s[HHE_MAXL];  // csum_c0: q_sp mod q_j and its Shoup quotient
     int m;              // csum_add: parents in this launch
     u64 *out;           // csum_digits: [B][L][K][N]
     const ModDev *mods;

@@ -986,7 +986,7 @@ HD void leaf_round_limbs(const LeafRoundArgs &a, size_t bk, size_t i, int j0, bo
         r[l] = ld2(a.r + (bk * M + l) * n + i);
 #pragma unroll
         for (int jj = 0; jj < JC; jj++)
-            if (with_c0 && j0 + jj < a.L)
+            if (with_c0 && a.base[l] && j0 + jj < a.L)
                 c0[l][jj] = ld2_galois(a.base[l] + (bk >> 1) * a.base_stride + (size_t)(j0 + jj) * n, (u32)i, a.logn, a.gal_einv[l], mod_at(a.mods, j0 + jj).q);
     }
 #pragma unroll
@@ -998,7 +998,7 @@ HD void leaf_round_limbs(const LeafRoundArgs &a, size_t bk, size_t i, int j0, bo
                 const ModDev mj = mod_at(a.mods, j);
                 ac[jj].a = addmod(ac[jj].a, submod(a.ks.half_mod[j], reduce64(r[l].a, mj), mj.q), mj.q);
                 ac[jj].b = addmod(ac[jj].b, submod(a.ks.half_mod[j], reduce64(r[l].b, mj), mj.q), mj.q);
-                if (with_c0) {  // k = 0: + q_sp * galois(c0)[j] (the sum is multiplied by q_sp^-1 when it is closed)
+                if (with_c0 && a.base[l]) {  // k = 0: + q_sp * galois(c0)[j] (the sum is multiplied by q_sp^-1 when it is closed); null: the c0 terms come from the per-element sums (csum_c0)
                     ac[jj].a = addmod(ac[jj].a, shoup_mul(c0[l][jj].a, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
                     ac[jj].b = addmod(ac[jj].b, shoup_mul(c0[l][jj].b, a.ks.qsp_mod[j], a.ks.qsp_mod_s[j], mj.q), mj.q);
                 }
@@ -1084,14 +1084,42 @@ HD void csum_add_body(const CsumArgs &a, size_t gid)
     const size_t bI = gid >> (a.logn - 1);
     const size_t b = bI / a.L, I = bI % a.L;
     if (b >= (size_t)a.B) return;
-    U2 s = ld2(a.sums + bI * n + i), v[HHE_LEAF_GROUP];
+    U2 s = ld2(a.sums + bI * n + i), v[HHE_LEAF_GROUP], s0 = {0, 0}, v0[HHE_LEAF_GROUP];
+    if (a.sums0) s0 = ld2(a.sums0 + bI * n + i);
 #pragma unroll
     for (int l = 0; l < HHE_LEAF_GROUP; l++)
-        if (l < a.m) v[l] = ld2(a.src[l] + b * a.src_stride + I * n + i);
+        if (l < a.m) {
+            v[l] = ld2(a.src[l] + b * a.src_stride + (a.L + I) * n + i);
+            if (a.sums0) v0[l] = ld2(a.src[l] + b * a.src_stride + I * n + i);
+        }
 #pragma unroll
     for (int l = 0; l < HHE_LEAF_GROUP; l++)
         if (l < a.m) { s.a = add_nw(s.a, v[l].a); s.b = add_nw(s.b, v[l].b); }
     st2(a.sums + bI * n + i, s);
+    if (a.sums0) {
+        const u64 q = mod_at(a.mods, (int)I).q;
+#pragma unroll
+        for (int l = 0; l < HHE_LEAF_GROUP; l++)
+            if (l < a.m) { s0.a = addmod(s0.a, v0[l].a, q); s0.b = addmod(s0.b, v0[l].b, q); }
+        st2(a.sums0 + bI * n + i, s0);
+    }
+}
+// gid over [B][L][N/2]: accH[b][0][j] += q_sp * galois(sums0[b][j])
+HD void csum_c0_body(const CsumArgs &a, size_t gid)
+{
+    const size_t n = (size_t)1 << a.logn;
+    const size_t i = (gid & ((n >> 1) - 1)) << 1;
+    const size_t bj = gid >> (a.logn - 1);
+    const size_t b = bj / a.L;
+    const int j = (int)(bj % a.L);
+    if (b >= (size_t)a.B) return;
+    const u64 q = mod_at(a.mods, j).q;
+    u64 *ap = a.accH + ((b * 2 + 0) * a.L + j) * n + i;
+    U2 acc = ld2(ap);
+    const U2 g = ld2_galois(a.sums0 + bj * n, (u32)i, a.logn, a.einv, q);
+    acc.a = addmod(acc.a, shoup_mul(g.a, a.qsp_mod[j], a.qsp_mod_s[j], q), q);
+    acc.b = addmod(acc.b, shoup_mul(g.b, a.qsp_mod[j], a.qsp_mod_s[j], q), q);
+    st2(ap, acc);
 }
 HD void csum_digits_body(const CsumArgs &a, size_t gid)
 {

@@ -498,6 +498,7 @@ __global__ void __launch_bounds__(ELT_THREADS) leaf_sum_kernel(LeafSumArgs a) { 
 __global__ void __launch_bounds__(ELT_THREADS) leaf_round_kernel(LeafRoundArgs a) { leaf_round_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) csum_add_kernel(CsumArgs a) { csum_add_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) csum_digits_kernel(CsumArgs a) { csum_digits_body(a, GID); }
+__global__ void __launch_bounds__(ELT_THREADS) csum_c0_kernel(CsumArgs a) { csum_c0_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) add_plain_kernel(AddPlainArgs a) { add_plain_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) encode_scatter_kernel(EncodeArgs a) { encode_scatter_body(a, GID); }
 __global__ void __launch_bounds__(ELT_THREADS) diag_kernel(DiagArgs a) { diag_body(a, GID); }
@@ -552,6 +553,7 @@ void k_ks_corr(const KsCorrArgs &a, rt_stream s) { LAUNCH1D(ks_corr_kernel, ((si
 void k_ks_finish(const KsFinishArgs &a, rt_stream s) { LAUNCH1D(ks_finish_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s) { LAUNCH1D(leaf_sum_kernel, ((size_t)a.B * 2 * a.L) << a.logn, s, a); }
 void k_csum_add(const CsumArgs &a, rt_stream s) { LAUNCH1D(csum_add_kernel, ((size_t)a.B * a.L) << (a.logn - 1), s, a); }
+void k_csum_c0(const CsumArgs &a, rt_stream s) { LAUNCH1D(csum_c0_kernel, ((size_t)a.B * a.L) << (a.logn - 1), s, a); }
 void k_csum_digits(const CsumArgs &a, rt_stream s) { LAUNCH1D(csum_digits_kernel, ((size_t)a.B * a.L) << (a.logn - 1), s, a); }
 void k_leaf_round(const LeafRoundArgs &a, rt_stream s) { LAUNCH1D(leaf_round_kernel, ((size_t)a.B * 2) << (a.logn - 1), s, a); }
 void k_add_plain(const AddPlainArgs &a, rt_stream s) { LAUNCH1D(add_plain_kernel, (size_t)a.B << a.logn, s, a); }

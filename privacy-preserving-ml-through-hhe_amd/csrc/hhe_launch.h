@@ -57,6 +57,7 @@ void k_ks_finish(const KsFinishArgs &a, rt_stream s);
 void k_leaf_sum(const LeafSumArgs &a, rt_stream s);
 void k_leaf_round(const LeafRoundArgs &a, rt_stream s);
 void k_csum_add(const CsumArgs &a, rt_stream s);      // FC leaves: integer sums of un-rotated c1 limbs per Galois element
+void k_csum_c0(const CsumArgs &a, rt_stream s);       // ... accH += q_sp * galois(sum of the parents' c0)
 void k_csum_digits(const CsumArgs &a, rt_stream s);   // ... and the digits of galois(sum) mod every key-level prime
 int k_ks_mac_leaves(const KsMacLeavesArgs &a, rt_stream s);  // -1: L > 4 (the caller takes the per-leaf path)
 void k_add_plain(const AddPlainArgs &a, rt_stream s);

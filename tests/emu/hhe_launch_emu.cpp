@@ -286,6 +286,7 @@ void k_ks_corr(const KsCorrArgs &a, rt_stream) { LOOP(((size_t)2 * a.K) << a.log
 void k_ks_finish(const KsFinishArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, ks_finish_body(a, (size_t)g)); }
 void k_leaf_sum(const LeafSumArgs &a, rt_stream) { LOOP(((size_t)a.B * 2 * a.L) << a.logn, leaf_sum_body(a, (size_t)g)); }
 void k_csum_add(const CsumArgs &a, rt_stream) { LOOP(((size_t)a.B * a.L) << (a.logn - 1), csum_add_body(a, (size_t)g)); }
+void k_csum_c0(const CsumArgs &a, rt_stream) { LOOP(((size_t)a.B * a.L) << (a.logn - 1), csum_c0_body(a, (size_t)g)); }
 void k_csum_digits(const CsumArgs &a, rt_stream) { LOOP(((size_t)a.B * a.L) << (a.logn - 1), csum_digits_body(a, (size_t)g)); }
 void k_leaf_round(const LeafRoundArgs &a, rt_stream) { LOOP(((size_t)a.B * 2) << (a.logn - 1), leaf_round_body(a, (size_t)g)); }
 void k_add_plain(const AddPlainArgs &a, rt_stream) { LOOP((size_t)a.B << a.logn, add_plain_body(a, (size_t)g)); }
