@@ -1167,13 +1167,14 @@ struct FcWalk {
         u32 elt;
         u64 *sums;      // [B][L][N] integer sums of c1 limbs
         u64 *sums0;     // [B][L][N] sums of c0 limbs mod q_j
+        unsigned char *carry;  // [B][L][N] wraps of `sums`
         int count = 0;  // leaves summed into `sums`
         int npend = 0;  // parents queued for the next csum_add launch
         int pend_slot[HHE_LEAF_GROUP];
         const u64 *pend_c1[HHE_LEAF_GROUP];
     };
     std::vector<ElemSum> esums;
-    static constexpr int CSUM_MAX = 15;   // integer sums of 15 terms below 2^60 fit 64 bits
+    static constexpr int CSUM_MAX = 2000;   // terms below 2^61: fewer than 255 wraps of the 64-bit word (CsumArgs::carry is a byte)
 
     int csum_add_pending(ElemSum &e)
     {
@@ -1181,7 +1182,7 @@ struct FcWalk {
         Lane &ln = *c->w;
         CsumArgs a;
         memset(&a, 0, sizeof(a));
-        a.sums = e.sums; a.sums0 = e.sums0; a.src_stride = 2 * (size_t)c->L * c->n; a.m = e.npend; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = c->L; a.K = c->K;
+        a.sums = e.sums; a.carry = e.carry; a.sums0 = e.sums0; a.src_stride = 2 * (size_t)c->L * c->n; a.m = e.npend; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = c->L; a.K = c->K;
         for (int l = 0; l < e.npend; l++) a.src[l] = e.pend_c1[l];
         k_csum_add(a, ln.stream);
         for (int l = 0; l < e.npend; l++) ln.fc_slots[e.pend_slot[l]].refs--;
@@ -1200,7 +1201,7 @@ struct FcWalk {
         const int L = c->L, K = c->K;
         CsumArgs a;
         memset(&a, 0, sizeof(a));
-        a.sums = e.sums; a.out = ln.ws_T; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K;
+        a.sums = e.sums; a.carry = e.carry; a.out = ln.ws_T; a.mods = c->d_mods; a.logn = c->logn; a.B = (int)B; a.L = L; a.K = K;
         a.einv = (u32)nt_invmod(e.elt, 2 * c->n); a.count = (u32)e.count;
         k_csum_digits(a, ln.stream);
         a.sums0 = e.sums0; a.accH = acc->accH;
@@ -1214,7 +1215,7 @@ struct FcWalk {
         mm.T = ln.ws_T; mm.key = it->second; mm.S = ln.ws_S; mm.mods = c->d_mods; mm.logn = c->logn; mm.B = (int)B; mm.L = L; mm.K = K;
         mm.s_acc = acc->accS; mm.perm_elt = 1; mm.corr = c->d_zero_corr;  // the digits are those of the ROTATED sum: identity map, no correction
         k_ks_mac(mm, ln.stream);
-        rt_memset(e.sums, 0, 2 * B * (size_t)L * c->n * 8, ln.stream);   // sums | sums0
+        rt_memset(e.sums, 0, B * (size_t)L * c->n * 17, ln.stream);   // sums | sums0 | carry
         e.count = 0;
         c->fc_csum_closes++;
         return HHE_OK;
@@ -1226,13 +1227,14 @@ struct FcWalk {
         for (auto &x : esums) if (x.elt == elt) e = &x;
         if (!e) {
             if (ln.csum_bufs.size() <= esums.size()) {
-                u64 *p = (u64 *)rt_malloc(2 * ln.fc_slot_cap * (size_t)c->L * c->n * 8);
+                u64 *p = (u64 *)rt_malloc(ln.fc_slot_cap * (size_t)c->L * c->n * 17);   // sums | sums0 | carry bytes
                 if (!p) return dev_fail("hhe_fc_row workspace");
                 ln.csum_bufs.push_back(p);
             }
             ElemSum x;
             x.elt = elt; x.sums = ln.csum_bufs[esums.size()]; x.sums0 = x.sums + B * (size_t)c->L * c->n;
-            rt_memset(x.sums, 0, 2 * B * (size_t)c->L * c->n * 8, ln.stream);
+            x.carry = (unsigned char *)(x.sums0 + B * (size_t)c->L * c->n);
+            rt_memset(x.sums, 0, B * (size_t)c->L * c->n * 17, ln.stream);
             esums.push_back(x);
             e = &esums.back();
         }

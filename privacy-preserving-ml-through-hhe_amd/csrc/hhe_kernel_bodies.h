@@ -1092,10 +1092,16 @@ HD void csum_add_body(const CsumArgs &a, size_t gid)
             v[l] = ld2(a.src[l] + b * a.src_stride + (a.L + I) * n + i);
             if (a.sums0) v0[l] = ld2(a.src[l] + b * a.src_stride + I * n + i);
         }
+    unsigned char *cp = a.carry + bI * n + i;
+    unsigned ca = cp[0], cb = cp[1];
 #pragma unroll
     for (int l = 0; l < HHE_LEAF_GROUP; l++)
-        if (l < a.m) { s.a = add_nw(s.a, v[l].a); s.b = add_nw(s.b, v[l].b); }
+        if (l < a.m) {
+            s.a += v[l].a; ca += s.a < v[l].a;
+            s.b += v[l].b; cb += s.b < v[l].b;
+        }
     st2(a.sums + bI * n + i, s);
+    cp[0] = (unsigned char)ca; cp[1] = (unsigned char)cb;
     if (a.sums0) {
         const u64 q = mod_at(a.mods, (int)I).q;
 #pragma unroll
@@ -1129,12 +1135,20 @@ HD void csum_digits_body(const CsumArgs &a, size_t gid)
     const size_t b = bI / a.L, I = bI % a.L;
     if (b >= (size_t)a.B) return;
     const u64 *src = a.sums + bI * n;
-    const u64 cq = (u64)a.count * mod_at(a.mods, (int)I).q;   // count <= 15, q < 2^60
+    const unsigned char *car = a.carry + bI * n;
+    const u64 qI = mod_at(a.mods, (int)I).q;
     const u32 j0 = (u32)(((u64)i * a.einv) & (2 * n - 1)), j1 = (u32)((j0 + a.einv) & (2 * n - 1));
-    const u64 v0 = j0 < n ? src[j0] : sub_nn(cq, src[j0 - n]), v1 = j1 < n ? src[j1] : sub_nn(cq, src[j1 - n]);
+    const bool f0 = j0 >= n, f1 = j1 >= n;   // sign flipped by the map: count * q_I - sum
+    const u32 p0 = f0 ? j0 - (u32)n : j0, p1 = f1 ? j1 - (u32)n : j1;
+    const u64 s0 = src[p0], s1 = src[p1], w0 = car[p0], w1 = car[p1];
     for (int J = 0; J < a.K; J++) {
         const ModDev mj = mod_at(a.mods, J);
-        st2(a.out + ((b * a.L + I) * a.K + J) * n + i, U2{reduce64(v0, mj), reduce64(v1, mj)});
+        const u64 t64 = reduce64(mj.nq, mj);                                 // 2^64 mod q_J
+        const u64 cq = mulmod((u64)a.count, reduce64(qI, mj), mj);           // count * q_I mod q_J
+        u64 d0 = addmod(reduce64(s0, mj), mulmod(w0, t64, mj), mj.q), d1 = addmod(reduce64(s1, mj), mulmod(w1, t64, mj), mj.q);
+        if (f0) d0 = submod(cq, d0, mj.q);
+        if (f1) d1 = submod(cq, d1, mj.q);
+        st2(a.out + ((b * a.L + I) * a.K + J) * n + i, U2{d0, d1});
     }
 }
 

@@ -185,9 +185,9 @@ def test_fc_row_naf_trie_equals_sequential_rotations(orc, api, emu_lib, mem):
 
 def test_fc_row_leaf_data_limbs_through_c1_sums(orc, api, emu_lib, mem, monkeypatch):
     """the data-limb sums of the leaf key switches come from per-Galois-element INTEGER sums of the parents' c1 (one inner product per
-    element; a sum is closed after 15 terms so that it stays below 2^64): with 400 inputs many leaves share an element, several sums are
-    closed early, and the words are the oracle's -- as they are with one inner product per leaf (HHE_FC_CSUM=0)"""
-    S = Setup(orc, 10, [50] * 4, all_galois=True)
+    element; 64-bit words + a byte that counts their wraps): with 400 inputs and 60-bit primes ~100 leaves share an element, the sums wrap
+    2^64 several times, and the words are the oracle's -- as they are with one inner product per leaf (HHE_FC_CSUM=0)"""
+    S = Setup(orc, 10, [60] * 4, all_galois=True)
     O = S.O
     rng = np.random.default_rng(9)
     n_in, B = 400, 2
@@ -205,7 +205,7 @@ def test_fc_row_leaf_data_limbs_through_c1_sums(orc, api, emu_lib, mem, monkeypa
         for b in range(B):
             assert (got[b] == refs[b]).all(), (knob, b)
         closes = X.query("fc_csum_closes")
-        assert (closes > 10) if knob == "1" else closes == 0   # more closes than distinct elements: the 15-term bound was hit
+        assert (0 < closes <= 2 * 8) if knob == "1" else closes == 0   # one close per distinct last-term element and chunk
         assert X.query("fc_fallbacks") == 0
         X.close()
 
