@@ -1170,8 +1170,8 @@ struct FcWalk {
         unsigned char *carry;  // [B][L][N] wraps of `sums`
         int count = 0;  // leaves summed into `sums`
         int npend = 0;  // parents queued for the next csum_add launch
-        int pend_slot[HHE_LEAF_GROUP];
-        const u64 *pend_c1[HHE_LEAF_GROUP];
+        int pend_slot[HHE_CSUM_GROUP];
+        const u64 *pend_c1[HHE_CSUM_GROUP];
     };
     std::vector<ElemSum> esums;
     static constexpr int CSUM_MAX = 2000;   // terms below 2^61: fewer than 255 wraps of the 64-bit word (CsumArgs::carry is a byte)
@@ -1243,7 +1243,7 @@ struct FcWalk {
         e->pend_slot[e->npend] = slot; e->pend_c1[e->npend] = parent;
         ++e->npend;
         ln.fc_slots[slot].refs++;
-        if (e->npend == HHE_LEAF_GROUP) return csum_add_pending(*e);
+        if (e->npend == c->fc_csum_group) return csum_add_pending(*e);
         return HHE_OK;
     }
 
@@ -1355,7 +1355,7 @@ int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int max_depth, c
         if (!(c->d_zero_corr = (u64 *)rt_malloc(bytes))) return dev_fail("hhe_fc_row workspace");
         rt_memset(c->d_zero_corr, 0, bytes, ln.stream);
     }
-    FcWalk w{c, trie, out, acc, B, group, max_depth + 1 + group + 2 * HHE_LEAF_GROUP, csum};
+    FcWalk w{c, trie, out, acc, B, group, max_depth + 1 + group + 3 * HHE_CSUM_GROUP, csum};
     w.esums.reserve(64);
     int root = -1, rc = w.acquire(&root);
     if (!rc) rc = w.walk(0, prod, root);

@@ -276,16 +276,17 @@ struct KsMacLeavesArgs {
 // element g uses the same key: sum_l sum_I NTT_J(d_I(galois_g(c1_l))) key_g[I][k][J] = sum_I NTT_J(D_I) key_g[I][k][J] with D_I = the integer
 // sum of the leaves' digits.  A digit of galois_g(c1) is c1_I at the mapped position, or q_I - c1_I where the map flips the sign (c1_I != 0:
 // the shared-digit zero flag covers the rest), so D_I = galois_g applied to the integer sum of the UN-rotated limbs with `count` q_I - . at
-// the flipped positions.  csum_add: sums[b][I][.] += c1 limbs of up to HHE_LEAF_GROUP parents (64-bit words + a byte counting the wraps);
+// the flipped positions.  csum_add: sums[b][I][.] += c1 limbs of up to HHE_CSUM_GROUP parents (64-bit words + a byte counting the wraps);
 // csum_digits: out[b][I][J][.] = D_I mod q_J for the K key-level primes -- the digit transforms and ONE inner product per element follow.
 // The leaves' q_sp * galois_g(c0) terms are linear mod q_j outright: sums0 collects the un-rotated c0 limbs of the same parents (mod q_j),
 // and csum_c0 adds q_sp * galois_g(sums0) into accH once per close -- the per-leaf coefficient-domain gather of c0 (8 bytes per cache
 // line) leaves the rounding kernel.
+constexpr int HHE_CSUM_GROUP = 8;  // parents per csum_add launch (the sums are read and written once per launch)
 struct CsumArgs {
     u64 *sums;          // [B][L][N] integer sums of un-rotated c1 limbs, low 64 bits
     unsigned char *carry;  // [B][L][N] how often a sum wrapped 2^64 (terms below 2^61: 255 wraps cover > 2000 leaves per element)
     u64 *sums0;         // [B][L][N] sums of un-rotated c0 limbs mod q_j (null: not collected)
-    const u64 *src[HHE_LEAF_GROUP];  // csum_add: parents' ciphertexts (item b at src[l] + b * src_stride: c0 limbs [L][N], then c1 limbs [L][N])
+    const u64 *src[HHE_CSUM_GROUP];  // csum_add: parents' ciphertexts (item b at src[l] + b * src_stride: c0 limbs [L][N], then c1 limbs [L][N])
     size_t src_stride;
     u64 *accH;          // csum_c0: [B][2][L][N]
     u64 qsp_mod[HHE_MAXL], qsp_mod_s[HHE_MAXL];  // csum_c0: q_sp mod q_j and its Shoup quotient

@@ -333,6 +333,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     if (const char *e = getenv("HHE_BLOCK_CACHE_MB")) c->block_cache_limit = (size_t)std::max(0, atoi(e)) << 20;
     if (const char *e = getenv("HHE_FC_ROWFUSED")) c->fc_row_fused = atoi(e);
     if (const char *e = getenv("HHE_FC_CSUM")) c->fc_csum = atoi(e);
+    if (const char *e = getenv("HHE_FC_CSUMGROUP")) c->fc_csum_group = std::max(1, std::min(HHE_CSUM_GROUP, atoi(e)));
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFGROUP")) c->fc_leaf_group = std::max(1, std::min(HHE_LEAF_GROUP, atoi(e)));
     if (const char *e = getenv("HHE_FC_SHARED")) c->fc_shared = atoi(e);

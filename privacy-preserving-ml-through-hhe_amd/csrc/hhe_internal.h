@@ -92,6 +92,7 @@ struct hhe_ctx {
     int fc_leaf_group = HHE_LEAF_GROUP;  // FC rotation trie: leaf key switches per launch, across the nodes whose digits are resident (HHE_FC_LEAFGROUP; 1 = one leaf at a time)
     int fc_row_fused = 1;          // FC non-leaf children at N >= 4096: inner product + inverse row pass in one kernel (ks_perm_row_kernel; HHE_FC_ROWFUSED=0: separate launches)
     u64 fc_csum_closes = 0;        // how many c1 sums were closed (digits + transforms + one inner product); diagnostics, hhe_ctx_query("fc_csum_closes")
+    int fc_csum_group = HHE_CSUM_GROUP;  // parents per csum_add launch (HHE_FC_CSUMGROUP, 1..HHE_CSUM_GROUP)
     int fc_csum = 1;               // FC leaves: data-limb sums through per-element integer sums of the parents' c1 (one inner product per element instead of one per leaf; HHE_FC_CSUM=0: per leaf)
     u64 *d_zero_corr = nullptr;    // [2][K][N] zeros: the correction table of the closing product of a c1 sum (its digits are already those of the rotated sum)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)

@@ -1084,10 +1084,10 @@ HD void csum_add_body(const CsumArgs &a, size_t gid)
     const size_t bI = gid >> (a.logn - 1);
     const size_t b = bI / a.L, I = bI % a.L;
     if (b >= (size_t)a.B) return;
-    U2 s = ld2(a.sums + bI * n + i), v[HHE_LEAF_GROUP], s0 = {0, 0}, v0[HHE_LEAF_GROUP];
+    U2 s = ld2(a.sums + bI * n + i), v[HHE_CSUM_GROUP], s0 = {0, 0}, v0[HHE_CSUM_GROUP];
     if (a.sums0) s0 = ld2(a.sums0 + bI * n + i);
 #pragma unroll
-    for (int l = 0; l < HHE_LEAF_GROUP; l++)
+    for (int l = 0; l < HHE_CSUM_GROUP; l++)
         if (l < a.m) {
             v[l] = ld2(a.src[l] + b * a.src_stride + (a.L + I) * n + i);
             if (a.sums0) v0[l] = ld2(a.src[l] + b * a.src_stride + I * n + i);
@@ -1095,7 +1095,7 @@ HD void csum_add_body(const CsumArgs &a, size_t gid)
     unsigned char *cp = a.carry + bI * n + i;
     unsigned ca = cp[0], cb = cp[1];
 #pragma unroll
-    for (int l = 0; l < HHE_LEAF_GROUP; l++)
+    for (int l = 0; l < HHE_CSUM_GROUP; l++)
         if (l < a.m) {
             s.a += v[l].a; ca += s.a < v[l].a;
             s.b += v[l].b; cb += s.b < v[l].b;
@@ -1105,7 +1105,7 @@ HD void csum_add_body(const CsumArgs &a, size_t gid)
     if (a.sums0) {
         const u64 q = mod_at(a.mods, (int)I).q;
 #pragma unroll
-        for (int l = 0; l < HHE_LEAF_GROUP; l++)
+        for (int l = 0; l < HHE_CSUM_GROUP; l++)
             if (l < a.m) { s0.a = addmod(s0.a, v0[l].a, q); s0.b = addmod(s0.b, v0[l].b, q); }
         st2(a.sums0 + bI * n + i, s0);
     }
