@@ -1354,6 +1354,7 @@ int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int max_depth, c
         const size_t bytes = (size_t)2 * c->K * c->n * 8;
         if (!(c->d_zero_corr = (u64 *)rt_malloc(bytes))) return dev_fail("hhe_fc_row workspace");
         rt_memset(c->d_zero_corr, 0, bytes, ln.stream);
+        if (rt_sync(ln.stream)) return dev_fail("hhe_fc_row workspace");   // once per context: chunks on other streams read the table too
     }
     FcWalk w{c, trie, out, acc, B, group, max_depth + 1 + group + 3 * HHE_CSUM_GROUP, csum};
     w.esums.reserve(64);
