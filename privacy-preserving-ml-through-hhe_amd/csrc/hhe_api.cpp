@@ -1097,7 +1097,8 @@ void fc_parent_digits(hhe_ctx *c, const u64 *parent, u64 *tp, size_t B, bool sp_
     k_ntt(a, false, c->w->stream);
 }
 // one child of a node from the node's shared digit transforms: leaf (sums only) or full ciphertext into `cur`
-int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const FcLeafAcc *leaf, u64 *cur, size_t B, u64 *add_to = nullptr)
+int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const FcLeafAcc *leaf, u64 *cur, size_t B, u64 *add_to = nullptr,
+                    const u64 *c0hat = nullptr)
 {
     auto it = c->gks->gk.find(elt);
     if (it == c->gks->gk.end()) return fail(HHE_ERR_NO_GALOIS_KEY, "Galois key not present");
@@ -1115,7 +1116,7 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
         KsRowArgs x;
         memset(&x, 0, sizeof(x));
         x.key = it->second; x.key_s = key_s; x.U0 = c->w->ws_S; x.U1 = c->w->ws_S + (size_t)L * n; x.u_stride = (size_t)2 * L * n; x.Usp = Usp;
-        x.B = (int)B; x.L = L; x.K = K; x.T = tp; x.corr = corr; x.perm_elt = elt;
+        x.B = (int)B; x.L = L; x.K = K; x.T = tp; x.corr = corr; x.perm_elt = elt; x.c0hat = c0hat;
         NttArgs g = ntt_args(c, nullptr, nullptr, 0, 0, K);
         if (k_ks_perm_row(g, x, c->w->stream)) return dev_fail("fc: key-switch row kernel");
         NttArgs as = ntt_args(c, Usp, Usp, B * 2, K - 1, 1);
@@ -1123,6 +1124,7 @@ int fc_child_shared(hhe_ctx *c, const u64 *parent, const u64 *tp, u32 elt, const
         k_ntt_pass(as, true, true, c->w->stream);
         NttArgs ad = ntt_args(c, c->w->ws_S, c->w->ws_S, B * 2 * L, 0, L);
         ad.store_op = STORE_KSF; ad.aux_r = Usp; ad.aux_in = parent; ad.base_stride = 2 * ln; ad.base_mask = 1; ad.gal_einv = einv; ad.aux_out = cur;
+        if (c0hat) { ad.aux_in = nullptr; ad.base_mask = 0; ad.gal_einv = 0; }   // galois(c0) is already inside S_0 (KsRowArgs::c0hat)
         ad.acc = add_to;
         k_ntt_pass(ad, true, true, c->w->stream);
         return HHE_OK;
@@ -1287,7 +1289,8 @@ struct FcWalk {
                 Lane::FcSlot sl;
                 sl.tp = (u64 *)rt_malloc(ln.fc_slot_cap * (size_t)c->L * c->K * c->n * 8);   // sized for the pool's capacity, not this call's batch
                 sl.ct = (u64 *)rt_malloc(ln.fc_slot_cap * c->ct_words() * 8);
-                if (!sl.tp || !sl.ct) { rt_free(sl.tp); rt_free(sl.ct); return dev_fail("hhe_fc_row workspace"); }
+                sl.c0hat = (u64 *)rt_malloc(ln.fc_slot_cap * (size_t)c->L * c->n * 8);
+                if (!sl.tp || !sl.ct || !sl.c0hat) { rt_free(sl.tp); rt_free(sl.ct); rt_free(sl.c0hat); return dev_fail("hhe_fc_row workspace"); }
                 sl.refs = 1;
                 ln.fc_slots.push_back(sl);
                 *slot = (int)ln.fc_slots.size() - 1;
@@ -1310,6 +1313,16 @@ struct FcWalk {
         // a node whose children are all leaves needs its digit transforms modulo the special prime only (their data limbs come from the c1 sums)
         fc_parent_digits(c, parent, ln.fc_slots[slot].tp, B, only_leaves);
         ln.fc_slots[slot].tp_polys = only_leaves ? 1 : c->K;
+        bool has_nonleaf = false;
+        for (int kid : trie[node].kids) has_nonleaf = has_nonleaf || !is_leaf(kid);
+        const u64 *c0hat = nullptr;
+        if (has_nonleaf && c->fc_c0hat && c->fc_row_fused && use_row_kernel(c)) {
+            // NTT form of the node's c0: its non-leaf children take galois(c0) through the NTT-domain map inside ks_perm_row_kernel
+            NttArgs t = ntt_args(c, parent, ln.fc_slots[slot].c0hat, B * c->L, 0, c->L);
+            t.src_item_polys = c->L; t.src_item_stride = c->ct_words();
+            k_ntt(t, false, ln.stream);
+            c0hat = ln.fc_slots[slot].c0hat;
+        }
         int rc;
         for (int kid : trie[node].kids) {
             if (!is_leaf(kid)) continue;
@@ -1327,7 +1340,7 @@ struct FcWalk {
             if ((rc = acquire(&k))) return rc;
             u64 *cur = ln.fc_slots[k].ct;
             // a child that is itself a term of the sum (distinct steps have distinct term sequences: mult is 0 or 1) is added in its own epilogue
-            if ((rc = fc_child_shared(c, parent, ln.fc_slots[slot].tp, elt, nullptr, cur, B, trie[kid].mult ? out : nullptr))) return rc;
+            if ((rc = fc_child_shared(c, parent, ln.fc_slots[slot].tp, elt, nullptr, cur, B, trie[kid].mult ? out : nullptr, c0hat))) return rc;
             for (int mm = 1; mm < trie[kid].mult; ++mm) op_add(c, out, cur, out, B, 2);
             if ((rc = walk(kid, cur, k))) return rc;
             ln.fc_slots[k].refs--;
@@ -1340,7 +1353,7 @@ int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int max_depth, c
     Lane &ln = *c->w;
     if (ln.fc_slot_cap < B) {  // slots of a smaller batch: start over
         rt_sync(ln.stream);
-        for (auto &sl : ln.fc_slots) { rt_free(sl.tp); rt_free(sl.ct); }
+        for (auto &sl : ln.fc_slots) { rt_free(sl.tp); rt_free(sl.ct); rt_free(sl.c0hat); }
         ln.fc_slots.clear();
         for (u64 *p : ln.csum_bufs) rt_free(p);
         ln.csum_bufs.clear();

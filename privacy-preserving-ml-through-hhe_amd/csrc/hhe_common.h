@@ -209,6 +209,8 @@ struct KsRowArgs {
     const u64 *T;
     const u64 *corr;
     u32 perm_elt;
+    const u64 *c0hat;    // optional [B][L][N]: NTT form of the node's c0.  q_sp * (c0hat read through the same map) joins S_0[j], so the mod-down
+                         // returns galois(c0) + the key-switched part and the KSF epilogue needs no coefficient-domain gather of c0
 };
 
 // Correction of the shared-digit key switch (DESIGN.md "FC rotation trie"): the digit d_I of galois_g(c1) differs from

@@ -333,6 +333,7 @@ extern "C" int hhe_ctx_create(int logn, int K, const uint64_t *q, uint64_t t, in
     if (const char *e = getenv("HHE_BLOCK_CACHE_MB")) c->block_cache_limit = (size_t)std::max(0, atoi(e)) << 20;
     if (const char *e = getenv("HHE_FC_ROWFUSED")) c->fc_row_fused = atoi(e);
     if (const char *e = getenv("HHE_FC_CSUM")) c->fc_csum = atoi(e);
+    if (const char *e = getenv("HHE_FC_C0HAT")) c->fc_c0hat = atoi(e);
     if (const char *e = getenv("HHE_FC_CSUMGROUP")) c->fc_csum_group = std::max(1, std::min(HHE_CSUM_GROUP, atoi(e)));
     if (const char *e = getenv("HHE_FC_LEAFSUM")) c->fc_leaf_sums = atoi(e);
     if (const char *e = getenv("HHE_FC_LEAFGROUP")) c->fc_leaf_group = std::max(1, std::min(HHE_LEAF_GROUP, atoi(e)));
@@ -363,7 +364,7 @@ static void free_lane(Lane &ln)
     rt_free(ln.ws_T); rt_free(ln.ws_S); rt_free(ln.ws_d); rt_free(ln.ws_ct3); rt_free(ln.ws_plain); rt_free(ln.ws_vals);
     for (auto &p : ln.ws_ct) { rt_free(p); p = nullptr; }
     rt_free(ln.ws_rot); ln.ws_rot = nullptr; ln.rot_cap = 0;
-    for (auto &sl : ln.fc_slots) { rt_free(sl.tp); rt_free(sl.ct); }
+    for (auto &sl : ln.fc_slots) { rt_free(sl.tp); rt_free(sl.ct); rt_free(sl.c0hat); }
     ln.fc_slots.clear(); ln.fc_slot_cap = 0;
     for (u64 *p : ln.csum_bufs) rt_free(p);
     ln.csum_bufs.clear();

@@ -52,7 +52,7 @@ struct Lane {   // one stream + the per-batch workspaces of the ops (capacity `c
     size_t rot_cap = 0;
     // FC shared digits: one slot per trie node that is still needed -- the digit transforms of its un-rotated c1 (tp [B][L][K][N]) and its
     // ciphertext (ct [B][2][L][N]); refs = 1 while the depth-first walk is below the node + 1 per queued leaf key switch that reads it
-    struct FcSlot { u64 *tp = nullptr, *ct = nullptr; int refs = 0; int tp_polys = 0; };  // tp_polys: K, or 1 when tp holds the special-prime transforms only
+    struct FcSlot { u64 *tp = nullptr, *ct = nullptr, *c0hat = nullptr; int refs = 0; int tp_polys = 0; };  // c0hat [B][L][N]: NTT form of the node's c0 (nodes with a non-leaf child)  // tp_polys: K, or 1 when tp holds the special-prime transforms only
     std::vector<FcSlot> fc_slots;
     std::vector<u64 *> csum_bufs;  // FC leaves: integer sums of parents' c1 per Galois element, [B][L][N] each (sized like the slots)
     size_t fc_slot_cap = 0;  // items the slots were sized for
@@ -93,6 +93,7 @@ struct hhe_ctx {
     int fc_row_fused = 1;          // FC non-leaf children at N >= 4096: inner product + inverse row pass in one kernel (ks_perm_row_kernel; HHE_FC_ROWFUSED=0: separate launches)
     u64 fc_csum_closes = 0;        // how many c1 sums were closed (digits + transforms + one inner product); diagnostics, hhe_ctx_query("fc_csum_closes")
     int fc_csum_group = HHE_CSUM_GROUP;  // parents per csum_add launch (HHE_FC_CSUMGROUP, 1..HHE_CSUM_GROUP)
+    int fc_c0hat = 1;              // FC non-leaf children through ks_perm_row_kernel: galois(c0) enters in the NTT domain (KsRowArgs::c0hat) instead of a gather in the KSF epilogue (HHE_FC_C0HAT=0)
     int fc_csum = 1;               // FC leaves: data-limb sums through per-element integer sums of the parents' c1 (one inner product per element instead of one per leaf; HHE_FC_CSUM=0: per leaf)
     u64 *d_zero_corr = nullptr;    // [2][K][N] zeros: the correction table of the closing product of a c1 sum (its digits are already those of the rotated sum)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)

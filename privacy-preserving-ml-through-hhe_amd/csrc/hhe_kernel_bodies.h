@@ -916,6 +916,22 @@ HD void ks_row_mac_gather(const KsRowArgs &x, const NttArgs &fa, int bx, int b, 
             acc0[2 * k] = add_nw(acc0[2 * k], c0.a); acc0[2 * k + 1] = add_nw(acc0[2 * k + 1], c0.b);
             acc1[2 * k] = add_nw(acc1[2 * k], c1.a); acc1[2 * k + 1] = add_nw(acc1[2 * k + 1], c1.b);
         }
+        if (x.c0hat && J < x.L) {   // + q_sp * NTT_J(galois(c0)) (canonical words: one more q on the bound above)
+            const u64 *ch = x.c0hat + ((size_t)b * x.L + J) * g.n;
+            const u64 w = fa.ks.qsp_mod[J], ws = fa.ks.qsp_mod_s[J];
+            U2 v[KSROW_NP];
+#pragma unroll
+            for (int k = 0; k < KSROW_NP; k++) {
+                const u32 p0 = ntt_perm_index((u32)ks_row_idx<CM, CC>(fa, g, tid, k).gi, fa.logn, x.perm_elt);
+                v[k] = ld2(ch + (p0 & ~1u));
+                if (p0 & 1) v[k] = U2{v[k].b, v[k].a};
+            }
+#pragma unroll
+            for (int k = 0; k < KSROW_NP; k++) {
+                acc0[2 * k] = add_nw(acc0[2 * k], shoup_mul(v[k].a, w, ws, m.q));
+                acc0[2 * k + 1] = add_nw(acc0[2 * k + 1], shoup_mul(v[k].b, w, ws, m.q));
+            }
+        }
     }
 }
 // sums -> LDS in [0,2q) (input range of the inverse rounds); optionally also canonical to global (S_0[j])
