@@ -57,5 +57,5 @@ def test_mnist_e2e_gpus_2_shards_samples_over_ranks(emu_lib):
     assert d["n_gpus"] == 2 and d["unit"] == "samples/s" and d["scaling"] == "weak"
     samples = d["value"] * d["ms_per_step"] * 1e-3 * d["steps"]
     assert abs(samples - 2) < 1e-6          # 1 sample per rank x 2 ranks
-    assert d["rank0"]["samples"] == 1 and d["roofline"]["key_switches_per_row_executed"] < d["roofline"]["key_switches_per_row_in_the_model"]
+    assert d["rank0"]["samples"] == 1 and d["roofline"]["key_switches_per_row_executed"] < d["roofline"]["reference_op_count"]["key_switches_per_row"]
     assert d["roofline"]["decompose"]["frac"] > 0 and d["config"]["sharding"].startswith("2 rank(s), contiguous sample ranges")
