@@ -1320,6 +1320,7 @@ struct FcWalk {
             // NTT form of the node's c0: its non-leaf children take galois(c0) through the NTT-domain map inside ks_perm_row_kernel
             NttArgs t = ntt_args(c, parent, ln.fc_slots[slot].c0hat, B * c->L, 0, c->L);
             t.src_item_polys = c->L; t.src_item_stride = c->ct_words();
+            t.store_op = STORE_MUL; t.mul = c->d_qsp_poly; t.mul_cycle = c->L;   // times q_sp: the sum it joins is divided by q_sp in the mod-down
             k_ntt(t, false, ln.stream);
             c0hat = ln.fc_slots[slot].c0hat;
         }
@@ -1361,6 +1362,12 @@ int fc_dfs_shared(hhe_ctx *c, const std::vector<NafNode> &trie, int max_depth, c
     }
     for (auto &sl : ln.fc_slots) sl.refs = 0;
     const int group = c->L <= 4 ? std::min(HHE_LEAF_GROUP, c->fc_leaf_group) : 1;  // k_ks_mac_leaves is instantiated for L <= 4
+    if (c->fc_c0hat && !c->d_qsp_poly) {
+        std::vector<u64> h((size_t)c->L * c->n);
+        for (int j = 0; j < c->L; j++) std::fill(h.begin() + (size_t)j * c->n, h.begin() + (size_t)(j + 1) * c->n, c->ksc.qsp_mod[j]);
+        if (!(c->d_qsp_poly = (u64 *)rt_malloc(h.size() * 8))) return dev_fail("hhe_fc_row workspace");
+        if (rt_h2d(c->d_qsp_poly, h.data(), h.size() * 8, ln.stream) || rt_sync(ln.stream)) return dev_fail("hhe_fc_row workspace");
+    }
     // the c1-sum scheme serves leaf sums (acc) with a group kernel (L <= 4); its zero table stands in for the correction of the closing product
     bool csum = acc && c->fc_csum && c->L <= 4;
     if (csum && !c->d_zero_corr) {

@@ -209,7 +209,7 @@ struct KsRowArgs {
     const u64 *T;
     const u64 *corr;
     u32 perm_elt;
-    const u64 *c0hat;    // optional [B][L][N]: NTT form of the node's c0.  q_sp * (c0hat read through the same map) joins S_0[j], so the mod-down
+    const u64 *c0hat;    // optional [B][L][N]: q_sp * NTT(the node's c0).  Read through the same map it joins S_0[j], so the mod-down
                          // returns galois(c0) + the key-switched part and the KSF epilogue needs no coefficient-domain gather of c0
 };
 

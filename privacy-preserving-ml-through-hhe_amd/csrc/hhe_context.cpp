@@ -441,6 +441,7 @@ extern "C" void hhe_ctx_destroy(hhe_ctx *c)
     for (auto &kv : c->d_key_shoup) rt_free(kv.second);
     rt_free(c->d_feistel_mask);
     rt_free(c->d_zero_corr);
+    rt_free(c->d_qsp_poly);
     rt_free(c->d_blocks); rt_free(c->d_flags);
     rt_free(c->d_tables); rt_free(c->d_mods); rt_free(c->d_behz); rt_free(c->d_slot_map);
     delete c;

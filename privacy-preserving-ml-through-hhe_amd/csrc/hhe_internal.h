@@ -95,6 +95,7 @@ struct hhe_ctx {
     int fc_csum_group = HHE_CSUM_GROUP;  // parents per csum_add launch (HHE_FC_CSUMGROUP, 1..HHE_CSUM_GROUP)
     int fc_c0hat = 1;              // FC non-leaf children through ks_perm_row_kernel: galois(c0) enters in the NTT domain (KsRowArgs::c0hat) instead of a gather in the KSF epilogue (HHE_FC_C0HAT=0)
     int fc_csum = 1;               // FC leaves: data-limb sums through per-element integer sums of the parents' c1 (one inner product per element instead of one per leaf; HHE_FC_CSUM=0: per leaf)
+    u64 *d_qsp_poly = nullptr;     // [L][N]: the constant q_sp mod q_j in every slot (multiplier of the NTT form of a node's c0, FcSlot::c0hat)
     u64 *d_zero_corr = nullptr;    // [2][K][N] zeros: the correction table of the closing product of a c1 sum (its digits are already those of the rotated sum)
     int fc_leaf_sums = 1;          // FC rotation trie: postpone the inverse transforms of leaf key switches (linear part summed first)
     size_t fc_chunk = 160;         // items per internal chunk of hhe_fc_row (0 = whole batch); ms per MNIST sample (784x10, 16 samples): 64: 60.5, 80: 60.6, 96: 60.6, 128: 59.5, 160: 58.4

@@ -916,9 +916,8 @@ HD void ks_row_mac_gather(const KsRowArgs &x, const NttArgs &fa, int bx, int b, 
             acc0[2 * k] = add_nw(acc0[2 * k], c0.a); acc0[2 * k + 1] = add_nw(acc0[2 * k + 1], c0.b);
             acc1[2 * k] = add_nw(acc1[2 * k], c1.a); acc1[2 * k + 1] = add_nw(acc1[2 * k + 1], c1.b);
         }
-        if (x.c0hat && J < x.L) {   // + q_sp * NTT_J(galois(c0)) (canonical words: one more q on the bound above)
+        if (x.c0hat && J < x.L) {   // + q_sp * NTT_J(galois(c0)): c0hat holds q_sp * NTT(c0) (canonical words: one more q on the bound above)
             const u64 *ch = x.c0hat + ((size_t)b * x.L + J) * g.n;
-            const u64 w = fa.ks.qsp_mod[J], ws = fa.ks.qsp_mod_s[J];
             U2 v[KSROW_NP];
 #pragma unroll
             for (int k = 0; k < KSROW_NP; k++) {
@@ -928,8 +927,8 @@ HD void ks_row_mac_gather(const KsRowArgs &x, const NttArgs &fa, int bx, int b, 
             }
 #pragma unroll
             for (int k = 0; k < KSROW_NP; k++) {
-                acc0[2 * k] = add_nw(acc0[2 * k], shoup_mul(v[k].a, w, ws, m.q));
-                acc0[2 * k + 1] = add_nw(acc0[2 * k + 1], shoup_mul(v[k].b, w, ws, m.q));
+                acc0[2 * k] = add_nw(acc0[2 * k], v[k].a);
+                acc0[2 * k + 1] = add_nw(acc0[2 * k + 1], v[k].b);
             }
         }
     }
