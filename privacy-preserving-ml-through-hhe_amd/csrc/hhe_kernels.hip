@@ -403,7 +403,10 @@ __global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_row_kernel(NttA
 // make a round trip (before: ks_mac_kernel wrote S, a row-pass launch read it back).  Same block order and outputs as the generic
 // variant of ks_row_kernel (U0 / U1 / Usp).
 template <int LOGM>
-__global__ void __launch_bounds__(KSROW_THREADS, KSROW_WAVES) ks_perm_row_kernel(NttArgs a, KsRowArgs x)
+#ifndef PERMROW_WAVES
+#define PERMROW_WAVES 3   // 154 VGPRs, no spills; at 4 waves per SIMD (128 VGPRs) 14 registers spill: 34.5 vs 32.5 ms per MNIST sample
+#endif
+__global__ void __launch_bounds__(KSROW_THREADS, PERMROW_WAVES) ks_perm_row_kernel(NttArgs a, KsRowArgs x)
 {
     constexpr bool TWL = LOGM == 8;
     __shared__ u64 lds[KSROW_LDS + (TWL ? KSROW_TWL : 0)];
